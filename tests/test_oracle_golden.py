@@ -1,0 +1,117 @@
+"""The CPU oracle against golden vectors captured from the real reference (tests/golden/make_golden.py)."""
+import numpy as np
+
+from oracle.detector_ref import detection_table, centers
+from oracle.planner_ref import PlannerRef, trajectory_length
+from oracle.tracker_ref import TrackerRef, iou_matrix, greedy_match
+
+
+def test_detector_matches_reference_bitwise(golden):
+    g = golden("detections")
+    for tag, (h, w) in {"720": (720, 1280), "480": (480, 640)}.items():
+        n, box, cls, conf = detection_table(1, 1100, h, w)
+        assert np.array_equal(n, g["n_" + tag])
+        assert np.array_equal(box, g["box_" + tag])
+        assert np.array_equal(cls, g["cls_" + tag])
+        assert np.array_equal(conf, g["conf_" + tag])          # float64, bit-for-bit
+    # seed wraps with frame_count % 1000 but positions depend on frame_count itself
+    assert not np.array_equal(g["box_720"][0], g["box_720"][1000])
+    assert np.array_equal(g["n_720"][0], g["n_720"][1000])
+
+
+def _replay(g, **kw):
+    trk = TrackerRef(**kw)
+    nfr = len(g["in_n"])
+    for f in range(nfr):
+        n = int(g["in_n"][f])
+        r = trk.update(n, g["in_box"][f], g["in_cls"][f], g["in_conf"][f])
+        t = trk.table(64)
+        assert t["n"] == g["n_live"][f], f
+        assert trk.next_id == g["next_id"][f]
+        assert np.array_equal(t["ids"], g["ids"][f]), f
+        assert np.array_equal(t["box"], g["box"][f]), f
+        assert np.array_equal(t["cls"], g["cls"][f]), f
+        assert np.array_equal(t["conf"], g["conf"][f]), f
+        assert np.array_equal(t["ahm"], g["ahm"][f]), f
+        assert np.array_equal(r["det2trk"], g["det2trk"][f][:n]), f
+        nm = int(g["n_match"][f])
+        assert [tuple(p) for p in g["match_pairs"][f][:nm]] == r["pairs"], f
+        conf_ids = trk.confirmed_ids()
+        assert conf_ids == list(g["conf_ids"][f][:g["n_conf"][f]]), f
+        key = "traj_%d" % (f + 1)
+        if key in g.files:
+            for k, row in enumerate(trk.rows):
+                tl, vl = g["traj_len_%d" % (f + 1)][k], g["vel_len_%d" % (f + 1)][k]
+                assert len(row["traj"]) == tl and len(row["vel"]) == vl
+                assert np.array_equal(np.array(row["traj"]), g[key][k, :tl])
+                if vl:
+                    assert np.array_equal(np.array(row["vel"]), g["vel_%d" % (f + 1)][k, :vl])
+    return trk
+
+
+def test_tracker_sim720_matches_reference(golden):
+    trk = _replay(golden("tracker_sim720"))
+    assert trk.next_id > 100          # many births/deaths exercised
+
+
+def test_tracker_ties_and_short_lifetimes(golden):
+    _replay(golden("tracker_ties"), iou_threshold=0.5, max_age=2, min_hits=1, trajectory_length=5)
+
+
+def test_iou_and_greedy_edge_cases():
+    assert iou_matrix([[0, 0, 10, 10]], [[10, 0, 20, 10]])[0, 0] == 0.0          # touching -> 0
+    assert iou_matrix([[0, 0, 0, 0]], [[0, 0, 0, 0]])[0, 0] == 0.0               # degenerate
+    assert iou_matrix([[0, 0, 10, 10]], [[0, 0, 10, 10]])[0, 0] == 1.0
+    m = np.array([[0.5, 0.5], [0.5, 0.5]])
+    assert greedy_match(m, 0.3) == [(0, 0), (1, 1)]                               # first in row-major order
+    assert greedy_match(np.array([[0.3]]), 0.3) == [(0, 0)]                       # max < thr is strict
+    assert greedy_match(np.zeros((0, 3)), 0.3) == []
+
+
+def _check_plan(p, state, wp=None, cost=None, order=None, obstacles=None):
+    r = p.plan(state, obstacles)
+    if wp is not None:
+        assert np.array_equal(r["wp"], wp)
+    assert np.array_equal(r["cost"], cost)
+    assert np.array_equal(r["order"], order)
+    return r
+
+
+def test_planner_matches_reference_bitwise(golden):
+    g = golden("planner")
+    p = PlannerRef()
+    for s, st in enumerate(g["states"]):
+        r = _check_plan(p, st, wp=g["wp_first8"][s] if s < 8 else None, cost=g["cost"][s], order=g["order"][s])
+        assert np.array_equal(r["types"], g["types"][s])
+        assert np.allclose(r["wp"].sum(axis=(0, 1)), g["wp_checksum"][s], rtol=1e-13)
+        ln = np.array([trajectory_length(w) for w in r["wp"]])
+        assert np.array_equal(ln, g["length"][s])
+        assert np.array_equal(r["wp"][:, -1, 4] - r["wp"][:, 0, 4], g["duration"][s])
+    # exact +/- ties are resolved by generation order
+    c0 = g["cost"][0]
+    assert c0[0] == c0[18] and list(g["order"][0]).index(0) < list(g["order"][0]).index(18)
+
+
+def test_planner_ref_path_and_obstacles(golden):
+    g = golden("planner")
+    obs = [tuple(o) for o in g["obstacles"]]
+    for tag, use_ref, use_obs in (("ref", True, False), ("obs", False, True), ("refobs", True, True)):
+        p = PlannerRef()
+        if use_ref:
+            p.set_reference_path(g["ref_path"])
+        for s in range(12):
+            _check_plan(p, g["states"][s], cost=g["cost_" + tag][s], order=g["order_" + tag][s],
+                        obstacles=obs if use_obs else None)
+
+
+def test_planner_non_default_construction(golden):
+    g = golden("planner")
+    p = PlannerRef(planning_horizon=3.0, dt=0.2, num_samples=5)
+    assert p.n == 16
+    for s in range(6):
+        _check_plan(p, g["states"][s], wp=g["alt_wp"][s], cost=g["alt_cost"][s], order=g["alt_order"][s])
+
+
+def test_detection_centers():
+    b = np.array([[0, 519, 104, 597]])
+    assert centers(b).tolist() == [[52.0, 558.0]]
