@@ -1,0 +1,192 @@
+/*
+ * avhot.h -- C ABI of libavhot.so: the MI355X (gfx950) hot path of the
+ * per-frame detect -> lane -> track -> Kalman -> plan loop.
+ *
+ * The reference (bhavyageethika/multimodal_autonomous_driving_perception_and_planning)
+ * is pure Python and has no FFI; the drop-in boundary is its five classes
+ * (SURVEY.md section 8b).  This header is what those classes' replacements
+ * bind through ctypes; each entry point names the reference method it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - Every function returns 0 (AV_OK) or a negative AV_E* code and never
+ *     throws; av_last_error_string() describes the last failure on this thread.
+ *   - All data pointers are DEVICE pointers unless the parameter is documented
+ *     as host.  The caller owns every buffer; the library owns only av_ctx
+ *     (constant tables, one side stream, captured graphs).  No allocation
+ *     happens on the per-frame path.
+ *   - `stream` is a hipStream_t passed as void*.  Calls are asynchronous and
+ *     stream-ordered.  An av_ctx is bound to one device and is not thread-safe.
+ *   - Batched layout: S independent video streams x W consecutive frames per
+ *     call ("window").  Sequential state (track table, Kalman state, detector
+ *     frame counter) lives in caller-owned device buffers and is advanced
+ *     in place; S=1, W=1 is the reference's per-frame call.
+ *   - Arithmetic that feeds a comparison is done in the reference's type and
+ *     operation order (int32 boxes, float64 everywhere else, no FMA contraction).
+ */
+#ifndef AVHOT_H
+#define AVHOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV_VERSION 100
+
+enum {
+    AV_OK = 0,
+    AV_EINVAL = -1,     /* bad argument (null pointer, capacity out of range, ...) */
+    AV_EHIP = -2,       /* a HIP runtime call failed; see av_last_error_string()     */
+    AV_ENODEV = -3,     /* no usable gfx950 device                                    */
+    AV_ESTATE = -4,     /* call order violated (e.g. planner used before configure)   */
+    AV_ENOMEM = -5
+};
+
+typedef struct av_ctx av_ctx;
+typedef void* av_stream_t;          /* hipStream_t */
+
+/* ---- context --------------------------------------------------------------------------------- */
+int av_version(void);
+const char* av_last_error_string(void);
+int av_device_count(int* count);                      /* host out */
+int av_ctx_create(int device, av_ctx** out);          /* fails with AV_ENODEV when no GPU is present */
+int av_ctx_destroy(av_ctx* ctx);
+int av_ctx_device(const av_ctx* ctx, int* device);
+
+/* Side stream for fork/join of independent stages (tracker || Kalman->planner), also valid inside
+ * a stream capture.  av_fork makes the side stream wait for everything enqueued on `main` so far;
+ * av_join makes `main` wait for the side stream. */
+int av_side_stream(av_ctx* ctx, av_stream_t* side);
+int av_fork(av_ctx* ctx, av_stream_t main);
+int av_join(av_ctx* ctx, av_stream_t main);
+
+/* hipGraph capture of a sequence of av_* calls issued on `stream` (must not be the null stream). */
+int av_graph_begin(av_ctx* ctx, av_stream_t stream);
+int av_graph_end(av_ctx* ctx, av_stream_t stream, int* graph_id);
+int av_graph_launch(av_ctx* ctx, int graph_id, av_stream_t stream);
+int av_graph_destroy(av_ctx* ctx, int graph_id);
+
+/* HIP events on arbitrary streams (bench.py times kernels on the stream they run on). */
+int av_event_create(void** ev);
+int av_event_destroy(void* ev);
+int av_event_record(void* ev, av_stream_t stream);
+int av_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int av_stream_sync(av_stream_t stream);
+
+/* ---- D1: simulated detector -------------------------------------------------------------------
+ * Replaces ObjectDetector.detect -> _detect_simulated (src/perception/detector.py:86-101,125-169).
+ * Detections are a pure function of (frame_count, h, w): the reference reseeds NumPy's legacy
+ * MT19937 with frame_count % 1000 per frame (:134).  The kernel re-derives that stream on device.
+ * frame_count[s] is the detector's counter BEFORE the window; frames frame_count[s]+1 .. +W are
+ * generated and frame_count[s] += W (detector.py:96).
+ *   det_n   [S][W]            number of detections (3..7)
+ *   det_box [S][W][dcap][4]   x1,y1,x2,y2 (int32)
+ *   det_cls [S][W][dcap]      class id 0..7
+ *   det_conf[S][W][dcap]      float64
+ * dcap >= 7.  status[s] != 0 if the MT19937 draw budget (227 words) was exceeded (never observed). */
+int av_simdet_generate(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int h, int w,
+                       int dcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box,
+                       int32_t* det_cls, double* det_conf, int32_t* status);
+
+/* ---- K1-K3: IoU tracker -----------------------------------------------------------------------
+ * Replaces MultiObjectTracker.update/_associate/_compute_iou
+ * (src/tracking/multi_object_tracker.py:84-105,113-164,166-241). */
+typedef struct {
+    double iou_threshold;        /* 0.3  (:62) ; must be >= 0 */
+    int32_t max_age;             /* 30   (:63) */
+    int32_t min_hits;            /* 3    (:64) */
+    int32_t trajectory_length;   /* 50   (:65) ; capacity of the per-track history ring */
+} av_tracker_cfg;
+
+/* One row of a track table, in dict-insertion (= ascending id) order.  64 bytes. */
+typedef struct {
+    int32_t id;
+    int32_t x1, y1, x2, y2;      /* last matched bbox (:192) */
+    int32_t cls;                 /* class at birth; never updated on match (:216-221) */
+    int32_t age, hits, misses;
+    int32_t slot;                /* index of this track's history ring in the stream's pool */
+    int32_t hist_len;            /* centres appended so far (birth included); ring index = k % L */
+    int32_t flags;               /* bit0: confirmed (hits >= min_hits) */
+    double conf;
+    double reserved;
+} av_track_row;
+
+/* Persistent per-stream tracker state (device).  Layout, for stream s with capacity tcap, L =
+ * trajectory_length, all 16-byte aligned:
+ *   int32 hdr[16]                  hdr[0]=n_tracks hdr[1]=next_id hdr[2]=frame_count hdr[3]=status
+ *   av_track_row rows[tcap]
+ *   double hist[tcap][L][4]        ring per slot: (cx, cy, vx, vy); entry k at k % L
+ * trajectory  = entries max(0,hist_len-L) .. hist_len-1        (cx, cy)
+ * velocities  = entries max(1,hist_len-L) .. hist_len-1        (vx, vy)
+ * status bit0: table overflow (more than tcap live tracks; births were dropped, parity lost). */
+size_t av_tracker_state_bytes(int tcap, int trajectory_length);
+int av_tracker_reset(av_ctx* ctx, av_stream_t stream, int n_streams, int tcap, int trajectory_length,
+                     void* state);
+/* tcap in {64,128,...,1024}; dcap <= 64.
+ *   snap    [S][W][tcap]   table after each frame (rows >= snap_n are unspecified); may be NULL
+ *   snap_n  [S][W]         live rows after each frame; may be NULL iff snap is NULL
+ *   det2trk [S][W][dcap]   id of the track detection j was matched to or born as (-1 beyond det_n) */
+int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg, int n_streams,
+                      int n_frames, int dcap, const int32_t* det_n, const int32_t* det_box,
+                      const int32_t* det_cls, const double* det_conf, int tcap, void* state,
+                      av_track_row* snap, int32_t* snap_n, int32_t* det2trk);
+
+/* ---- E1-E3: vehicle state estimator ------------------------------------------------------------
+ * Replaces VehicleStateEstimator.predict/update/step/_extract_state
+ * (src/state_estimation/vehicle_state.py:68-198) incl. filterpy's predict/update equations. */
+typedef struct {
+    double dt;                   /* 0.033 (:49) */
+    double process_noise;        /* 0.1   (:50) */
+    double measurement_noise;    /* 1.0   (:51) */
+} av_kf_cfg;
+
+#define AV_KF_STATE_DOUBLES 48   /* x[6], P[36] row-major, prev_heading, prev_speed, time, 3 spare */
+#define AV_VSTATE_DOUBLES 12     /* x y vx vy heading speed acceleration yaw_rate timestamp
+                                    pos_uncertainty vel_uncertainty heading_uncertainty(=0) */
+int av_kf_reset(av_ctx* ctx, av_stream_t stream, int n_streams, double* kf_state);
+/* mode per (stream, frame): 0 = predict only (VehicleStateEstimator.predict)
+ *                           1 = step(z)      (predict + update)
+ *                           2 = step(None)   (predict + second extract)
+ *                           3 = update(z) only
+ * mode == NULL means 1 everywhere.
+ *   z          [S][W][4]
+ *   out_state  [S][W][12]
+ *   plan_state [S][W][4]   (x, y, heading, speed) = the tuple demo.py:118-119 builds; may be NULL */
+int av_kf_step(av_ctx* ctx, av_stream_t stream, const av_kf_cfg* cfg, int n_streams, int n_frames,
+               const double* z, const uint8_t* mode, double* kf_state, double* out_state,
+               double* plan_state);
+
+/* ---- P1-P3: motion planner ---------------------------------------------------------------------
+ * Replaces MotionPlanner.generate_polynomial_trajectory / evaluate_trajectory_cost / plan
+ * (src/planning/motion_planner.py:126-204,206-262,264-303). */
+typedef struct {
+    double planning_horizon;     /* 5.0 (:69) */
+    double dt;                   /* 0.1 (:70) */
+    int32_t num_samples;         /* 7   (:71) lateral samples; candidates = 3 * num_samples */
+    int32_t reserved;
+    double w_lateral, w_velocity, w_acceleration, w_curvature;   /* 1.0 0.5 0.3 0.4 (:85-89) */
+} av_planner_cfg;
+
+#define AV_WP_DOUBLES 6          /* x y heading velocity timestamp curvature */
+/* Builds the per-configuration constant tables (timestamps, 1-exp(-t), quintic blend, lateral
+ * offsets) on the host and uploads them.  n_points = int(H/dt)+1 <= 1024, candidates <= 192. */
+int av_planner_configure(av_ctx* ctx, const av_planner_cfg* cfg);
+int av_planner_dims(const av_ctx* ctx, int* n_points, int* n_candidates);   /* host out */
+/* One plan() per start state.  n_states = S*W.
+ *   state     [n_states][4]          x, y, heading, speed
+ *   ref_path  [n_ref][2] or NULL     shared by all states of this call (set_reference_path, :93-124)
+ *   obstacles [n_obs][3] or NULL     (x, y, radius), shared by all states of this call
+ *   waypoints [n_states][C][n][6]    GENERATION order (lateral outer, speed inner); may be NULL
+ *   cost      [n_states][C]          generation order
+ *   order     [n_states][C]          order[r] = generation index of the r-th cheapest (stable sort) */
+int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double* state,
+                    const double* ref_path, int n_ref, const double* obstacles, int n_obs,
+                    double* waypoints, double* cost, int32_t* order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVHOT_H */

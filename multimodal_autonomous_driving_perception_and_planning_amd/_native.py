@@ -1,0 +1,202 @@
+"""ctypes binding of libavhot.so (include/avhot.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device
+is visible when a context is requested, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavhot.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("iou_threshold", C.c_double), ("max_age", C.c_int32), ("min_hits", C.c_int32),
+                ("trajectory_length", C.c_int32)]
+
+
+class KfCfg(C.Structure):
+    _fields_ = [("dt", C.c_double), ("process_noise", C.c_double), ("measurement_noise", C.c_double)]
+
+
+class PlannerCfg(C.Structure):
+    _fields_ = [("planning_horizon", C.c_double), ("dt", C.c_double), ("num_samples", C.c_int32),
+                ("reserved", C.c_int32), ("w_lateral", C.c_double), ("w_velocity", C.c_double),
+                ("w_acceleration", C.c_double), ("w_curvature", C.c_double)]
+
+
+class LaneCfg(C.Structure):
+    _fields_ = [("hough_threshold", C.c_int32), ("min_line_length", C.c_int32), ("max_line_gap", C.c_int32),
+                ("max_segments", C.c_int32), ("smoothing_factor", C.c_double)]
+
+
+# numpy structured dtype mirroring av_track_row (64 bytes)
+TRACK_ROW_FIELDS = [("id", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("cls", "<i4"),
+                    ("age", "<i4"), ("hits", "<i4"), ("misses", "<i4"), ("slot", "<i4"), ("hist_len", "<i4"),
+                    ("flags", "<i4"), ("conf", "<f8"), ("reserved", "<f8")]
+TRACK_ROW_BYTES = 64
+TRACKER_HDR_BYTES = 64
+KF_STATE_DOUBLES = 48
+VSTATE_DOUBLES = 12
+WP_DOUBLES = 6
+
+# (name, restype, argtypes); everything returns int status except the three noted
+_SIGS = [
+    ("av_version", C.c_int, []),
+    ("av_last_error_string", C.c_char_p, []),
+    ("av_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("av_ctx_create", C.c_int, [C.c_int, C.POINTER(vp)]),
+    ("av_ctx_destroy", C.c_int, [vp]),
+    ("av_ctx_device", C.c_int, [vp, C.POINTER(C.c_int)]),
+    ("av_side_stream", C.c_int, [vp, C.POINTER(vp)]),
+    ("av_fork", C.c_int, [vp, vp]),
+    ("av_join", C.c_int, [vp, vp]),
+    ("av_graph_begin", C.c_int, [vp, vp]),
+    ("av_graph_end", C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+    ("av_graph_launch", C.c_int, [vp, C.c_int, vp]),
+    ("av_graph_destroy", C.c_int, [vp, C.c_int]),
+    ("av_event_create", C.c_int, [C.POINTER(vp)]),
+    ("av_event_destroy", C.c_int, [vp]),
+    ("av_event_record", C.c_int, [vp, vp]),
+    ("av_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    ("av_stream_sync", C.c_int, [vp]),
+    ("av_simdet_generate", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    ("av_tracker_state_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("av_tracker_reset", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    ("av_tracker_update", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
+                                    C.c_int, vp, vp, vp, vp]),
+    ("av_kf_reset", C.c_int, [vp, vp, C.c_int, vp]),
+    ("av_kf_step", C.c_int, [vp, vp, C.POINTER(KfCfg), C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    ("av_planner_configure", C.c_int, [vp, C.POINTER(PlannerCfg)]),
+    ("av_planner_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("av_planner_plan", C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
+]
+
+# entry points added by later translation units; bound when present in the header list below
+_OPTIONAL_SIGS = []
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name include/avhot.h declares (parsed from the header text)."""
+    import re
+
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "avhot.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(av_[a-z0-9_]+)\s*\(", txt)))
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  libavhot.so
+    NEEDs libamdhip64.so.7 too; if the system copy under /opt/rocm were mapped first, torch would
+    later map its bundled copy as a second runtime, and the two do not share devices, streams or
+    allocations.  Mapping torch's copy first makes the dynamic loader satisfy our NEEDED entry
+    with it (SONAME match).
+    """
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
+def lib():
+    """The loaded library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libavhot.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "-- this package has no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGS + _OPTIONAL_SIGS:
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def register(sigs):
+    """Used by lane/yolo bindings to add their signatures before first use."""
+    global _lib
+    _OPTIONAL_SIGS.extend(sigs)
+    if _lib is not None:
+        for name, res, args in sigs:
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libavhot: %s (code %d)" % (lib().av_last_error_string().decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """Owns one av_ctx on one device."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = vp()
+        check(L.av_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        s = vp()
+        check(L.av_side_stream(h, C.byref(s)))
+        self.side_stream = s
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().av_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (the per-frame drop-in classes share it)."""
+    c = _default_ctx.get(device)
+    if c is None or c.handle is None:
+        c = Context(device)
+        _default_ctx[device] = c
+    return c
+
+
+def stream_handle(stream=None):
+    """hipStream_t of a torch stream (default: torch's current stream) as c_void_p."""
+    import torch
+
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)

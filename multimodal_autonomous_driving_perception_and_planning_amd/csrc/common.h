@@ -1,0 +1,80 @@
+// Internal helpers shared by the libavhot.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "avhot.h"
+
+struct PlannerTables;
+
+struct av_ctx {
+    int device = -1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // planner
+    bool planner_ready = false;
+    av_planner_cfg pcfg{};
+    int n_points = 0, n_lat = 0, n_cand = 0;
+    double* d_ptab = nullptr;          // device: t[n] | alpha[n] | q[n] | dtdiff[n] | lat[n_lat]
+    // simulated detector: class cdf (8 doubles)
+    double* d_cdf = nullptr;
+    std::vector<hipGraphExec_t> graphs;
+    // lane / yolo sub-contexts are attached by their own translation units
+    void* lane = nullptr;
+    void* yolo = nullptr;
+};
+
+void av_set_error(const char* fmt, ...);
+
+#define AV_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            av_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return AV_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+#define AV_REQUIRE(cond, code, ...)   \
+    do {                              \
+        if (!(cond)) {                \
+            av_set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+#define AV_LAUNCH_CHECK()                                                                \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            av_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return AV_EHIP;                                                              \
+        }                                                                                \
+    } while (0)
+
+static inline hipStream_t as_stream(av_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- wave64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

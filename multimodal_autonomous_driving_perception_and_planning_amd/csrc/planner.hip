@@ -1,0 +1,289 @@
+// P1-P3: batched candidate-trajectory planner.
+//
+// Reference: MotionPlanner (src/planning/motion_planner.py)
+//   generate_polynomial_trajectory :126-204, evaluate_trajectory_cost :206-262, plan :264-303.
+//
+// Data layout (HBM):  waypoints [n_states][C][n][6] float64, AoS per waypoint
+//   (x, y, heading, velocity, timestamp, curvature) -- the field order of the Waypoint dataclass --
+//   so one trajectory is one contiguous n*48-byte run; cost/order [n_states][C].
+//
+// Mapping: a 256-thread workgroup owns G consecutive start states.
+//   phase 1  3*G lanes run the sequential part the reference has per speed option: the velocity
+//            blend, the prefix sum s_i = s_{i-1} + v_i*dt (:156-157) and the velocity/acceleration
+//            cost accumulated left to right (:235-244).  These depend only on (v0, vt) and are
+//            shared by the num_samples lateral offsets.  G more lanes take cos/sin of the heading.
+//   phase 2  each wave takes whole trajectories; lane = waypoint.  Positions, tangent heading
+//            (atan2 of the forward difference), curvature and the per-waypoint cost terms are
+//            computed in registers, the AoS image of the trajectory is assembled in a per-wave LDS
+//            tile, and the tile is streamed out as contiguous 16-byte-per-lane stores (the kernel's
+//            HBM traffic is these stores: 48 B per waypoint).
+//   phase 3  stable rank of the C costs (== Python's stable sort, :300).
+// All arithmetic is float64 in the reference's operation order; the library is built with
+// -ffp-contract=off so a*b+c stays two roundings like NumPy scalar code.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+struct PlanParams {
+    int n, n_lat, C;
+    double dt, H;
+    double w_lat, w_vel, w_acc, w_curv;
+    const double *t, *alpha, *q, *dtd, *lat;
+};
+
+__host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
+
+// doubles of dynamic LDS for a given G
+__host__ __device__ inline size_t plan_lds_doubles(int G, int n, int C) {
+    return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + even_up(G * C) + (size_t)4 * n * 6;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states, const double* __restrict__ state,
+                                                      const double* __restrict__ ref, int n_ref,
+                                                      const double* __restrict__ obs, int n_obs,
+                                                      double* __restrict__ wp, double* __restrict__ cost,
+                                                      int32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = p.n, C = p.C;
+    double* vs = sm;                                   // [G][3][n][2]  (v, s)
+    double* base = vs + (size_t)G * 3 * n * 2;         // [G][3][3]     S_v, S_a, running(S_v then acc terms)
+    double* trig = base + even_up(G * 3 * 3);          // [G][8]        x0 y0 cos sin cos(h+pi/2) sin(h+pi/2) h0
+    double* costs = trig + G * 8;                      // [G][C]
+    double* stage_all = costs + even_up(G * C);        // [4][n*6]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int f0 = blockIdx.x * G;
+
+    // ---- phase 1 ---------------------------------------------------------------------------------
+    if (tid < G * 3) {
+        const int g = tid / 3, k = tid - g * 3, f = f0 + g;
+        if (f < n_states) {
+            const double v0 = state[(size_t)f * 4 + 3];
+            const double vt = 8.0 + 2.0 * (double)k;          // [8.0, 10.0, 12.0]  (:280)
+            const double dv = vt - v0;
+            double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
+            double s = 0.0, sv = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double v = v0 + dv * p.alpha[i];          // :153-154
+                if (i > 0) s = s + v * p.dt;                    // :157
+                o[2 * i] = v, o[2 * i + 1] = s;
+                const double e = v - 10.0;
+                sv = sv + p.w_vel * (e * e);                    // :236
+            }
+            double run = sv, sa = 0.0;
+            for (int i = 1; i < n; ++i) {
+                const double dtt = p.dtd[i];
+                if (dtt > 0.0) {
+                    const double a = (o[2 * i] - o[2 * (i - 1)]) / dtt;
+                    const double term = p.w_acc * (a * a);      // :244
+                    run = run + term;
+                    sa = sa + term;
+                }
+            }
+            double* b = base + (g * 3 + k) * 3;
+            b[0] = sv, b[1] = sa, b[2] = run;
+        }
+    } else if (tid >= 64 && tid < 64 + G) {
+        const int g = tid - 64, f = f0 + g;
+        if (f < n_states) {
+            const double h0 = state[(size_t)f * 4 + 2];
+            const double hp = h0 + 1.5707963267948966;           // heading0 + np.pi/2  (:179)
+            double* tg = trig + g * 8;
+            tg[0] = state[(size_t)f * 4 + 0], tg[1] = state[(size_t)f * 4 + 1];
+            tg[2] = cos(h0), tg[3] = sin(h0), tg[4] = cos(hp), tg[5] = sin(hp), tg[6] = h0;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2 ---------------------------------------------------------------------------------
+    double* stage = stage_all + (size_t)wid * n * 6;
+    for (int j = wid; j < G * C; j += 4) {
+        const int g = j / C, c = j - g * C, f = f0 + g;
+        if (f >= n_states) continue;
+        const int li = c / 3, k = c - li * 3;
+        const double df = p.lat[li];
+        const double* tg = trig + g * 8;
+        const double x0 = tg[0], y0 = tg[1], cs = tg[2], sn = tg[3], c2 = tg[4], s2 = tg[5], h0 = tg[6];
+        const double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
+
+        for (int i = lane; i < n; i += 64) {
+            const double v = o[2 * i], s = o[2 * i + 1];
+            const double d = df * p.q[i];
+            double x = x0 + s * cs, y = y0 + s * sn;            // :175-176
+            x = x + d * c2, y = y + d * s2;                     // :179-180
+            double hd = 0.0;
+            if (i < n - 1) {
+                const double s1 = o[2 * i + 3], d1 = df * p.q[i + 1];
+                double x1 = x0 + s1 * cs, y1 = y0 + s1 * sn;
+                x1 = x1 + d1 * c2, y1 = y1 + d1 * s2;
+                hd = atan2(y1 - y, x1 - x);                     // :188
+            }
+            double* w = stage + (size_t)i * 6;
+            w[0] = x, w[1] = y, w[2] = hd, w[3] = v, w[4] = p.t[i], w[5] = 0.0;
+        }
+        wave_lds_fence();
+        double lat_sum = 0.0, curv_sum = 0.0, obs_sum = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            double* w = stage + (size_t)i * 6;
+            double curv = 0.0;
+            if (i > 0 && i < n - 1) {
+                const double hp = stage[(size_t)(i - 1) * 6 + 2];
+                curv = (w[2] - hp) / (w[3] * p.dt + 1e-6);      // :196
+                w[5] = curv;
+            }
+            curv_sum += p.w_curv * (curv * curv);               // :248
+            const double x = w[0], y = w[1];
+            if (n_ref > 0) {                                    // :229-231
+                double md = INFINITY;
+                for (int r = 0; r < n_ref; ++r) {
+                    const double dx = ref[2 * r] - x, dy = ref[2 * r + 1] - y;
+                    const double dd = sqrt(dx * dx + dy * dy);
+                    md = dd < md ? dd : md;
+                }
+                lat_sum += p.w_lat * (md * md);
+            }
+            for (int q = 0; q < n_obs; ++q) {                   // :253-259
+                const double ox = obs[3 * q], oy = obs[3 * q + 1], rad = obs[3 * q + 2];
+                const double ex = x - ox, ey = y - oy;
+                const double dist = sqrt(ex * ex + ey * ey);
+                if (dist < rad * 2.0) obs_sum += 1000.0 * (rad * 2.0 - dist);
+                else if (dist < rad * 4.0) obs_sum += 10.0 / (dist - rad + 0.1);
+            }
+        }
+        wave_lds_fence();
+        if (lane == 0) stage[(size_t)(n - 1) * 6 + 2] = n > 1 ? stage[(size_t)(n - 2) * 6 + 2] : h0;   // :190
+        lat_sum = wave_sum(lat_sum), curv_sum = wave_sum(curv_sum), obs_sum = wave_sum(obs_sum);
+        if (lane == 0) {
+            const double* b = base + (g * 3 + k) * 3;
+            // reference accumulates [ref-path] -> velocity -> acceleration -> curvature -> obstacles
+            const double va = n_ref > 0 ? (lat_sum + b[0]) + b[1] : b[2];
+            costs[g * C + c] = (va + curv_sum) + obs_sum;
+        }
+        wave_lds_fence();
+        if (wp) {
+            const double2* src = reinterpret_cast<const double2*>(stage);
+            double2* dst = reinterpret_cast<double2*>(wp + ((size_t)f * C + c) * n * 6);
+            for (int q = lane; q < n * 3; q += 64) dst[q] = src[q];
+        }
+        wave_lds_fence();
+    }
+    __syncthreads();
+
+    // ---- phase 3: stable ascending rank (:300) -----------------------------------------------------
+    for (int idx = tid; idx < G * C; idx += 256) {
+        const int g = idx / C, c = idx - g * C, f = f0 + g;
+        if (f >= n_states) continue;
+        const double* cc = costs + g * C;
+        const double mine = cc[c];
+        int rank = 0;
+        for (int o2 = 0; o2 < C; ++o2) {
+            const double v = cc[o2];
+            rank += (v < mine || (v == mine && o2 < c)) ? 1 : 0;
+        }
+        cost[(size_t)f * C + c] = mine;
+        order[(size_t)f * C + rank] = c;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int av_planner_configure(av_ctx* ctx, const av_planner_cfg* cfg) {
+    AV_REQUIRE(ctx && cfg, AV_EINVAL, "av_planner_configure: null argument");
+    AV_REQUIRE(cfg->dt > 0.0 && cfg->planning_horizon > 0.0, AV_EINVAL, "av_planner_configure: dt and horizon must be > 0");
+    AV_REQUIRE(cfg->num_samples >= 1 && cfg->num_samples <= 64, AV_EINVAL,
+               "av_planner_configure: num_samples %d not in [1,64]", cfg->num_samples);
+    const double H = cfg->planning_horizon;
+    const int n = (int)(H / cfg->dt) + 1;                               // :143
+    AV_REQUIRE(n >= 1 && n <= 256, AV_EINVAL, "av_planner_configure: %d waypoints per trajectory not in [1,256]", n);
+    const int nl = cfg->num_samples;
+    std::vector<double> tab((size_t)4 * n + nl);
+    double *t = tab.data(), *alpha = t + n, *q = alpha + n, *dtd = q + n, *lat = dtd + n;
+    // numpy.linspace(0, H, n): arange * step + start, last element forced to stop      (:144)
+    if (n == 1) {
+        t[0] = 0.0;
+    } else {
+        const double step = (H - 0.0) / (double)(n - 1);
+        for (int i = 0; i < n; ++i) t[i] = (step == 0.0 ? ((double)i / (double)(n - 1)) * H : (double)i * step) + 0.0;
+        t[n - 1] = H;
+    }
+    for (int i = 0; i < n; ++i) {
+        alpha[i] = 1.0 - std::exp(-t[i]);                                // :153
+        double tau = t[i] / H;                                           // :166-167
+        tau = tau < 0.0 ? 0.0 : (tau > 1.0 ? 1.0 : tau);
+        q[i] = 10.0 * std::pow(tau, 3.0) - 15.0 * std::pow(tau, 4.0) + 6.0 * std::pow(tau, 5.0);   // :169
+        dtd[i] = i > 0 ? t[i] - t[i - 1] : 0.0;
+    }
+    if (nl == 1) {
+        lat[0] = -3.5;                                                   // linspace(-3.5, 3.5, 1)
+    } else {
+        const double step = (3.5 - (-3.5)) / (double)(nl - 1);           // :279
+        for (int i = 0; i < nl; ++i) lat[i] = (double)i * step + (-3.5);
+        lat[nl - 1] = 3.5;
+    }
+    AV_HIP(hipSetDevice(ctx->device));
+    if (ctx->d_ptab) {
+        AV_HIP(hipFree(ctx->d_ptab));
+        ctx->d_ptab = nullptr;
+    }
+    AV_HIP(hipMalloc(&ctx->d_ptab, tab.size() * sizeof(double)));
+    AV_HIP(hipMemcpy(ctx->d_ptab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->pcfg = *cfg;
+    ctx->n_points = n, ctx->n_lat = nl, ctx->n_cand = 3 * nl;
+    ctx->planner_ready = true;
+    return AV_OK;
+}
+
+int av_planner_dims(const av_ctx* ctx, int* n_points, int* n_candidates) {
+    AV_REQUIRE(ctx && n_points && n_candidates, AV_EINVAL, "av_planner_dims: null argument");
+    AV_REQUIRE(ctx->planner_ready, AV_ESTATE, "av_planner_dims: call av_planner_configure first");
+    *n_points = ctx->n_points, *n_candidates = ctx->n_cand;
+    return AV_OK;
+}
+
+int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double* state, const double* ref_path,
+                    int n_ref, const double* obstacles, int n_obs, double* waypoints, double* cost, int32_t* order) {
+    AV_REQUIRE(ctx && state && cost && order, AV_EINVAL, "av_planner_plan: null argument");
+    AV_REQUIRE(ctx->planner_ready, AV_ESTATE, "av_planner_plan: call av_planner_configure first");
+    AV_REQUIRE(n_states > 0, AV_EINVAL, "av_planner_plan: n_states must be > 0");
+    AV_REQUIRE(n_ref >= 0 && n_obs >= 0 && (n_ref == 0 || ref_path) && (n_obs == 0 || obstacles), AV_EINVAL,
+               "av_planner_plan: ref_path/obstacles pointer missing");
+    AV_REQUIRE(n_ref != 1, AV_EINVAL, "av_planner_plan: a reference path needs >= 2 points (set_reference_path ignores shorter)");
+    const int n = ctx->n_points, C = ctx->n_cand;
+    PlanParams p;
+    p.n = n, p.n_lat = ctx->n_lat, p.C = C;
+    p.dt = ctx->pcfg.dt, p.H = ctx->pcfg.planning_horizon;
+    p.w_lat = ctx->pcfg.w_lateral, p.w_vel = ctx->pcfg.w_velocity, p.w_acc = ctx->pcfg.w_acceleration;
+    p.w_curv = ctx->pcfg.w_curvature;
+    p.t = ctx->d_ptab, p.alpha = p.t + n, p.q = p.alpha + n, p.dtd = p.q + n, p.lat = p.dtd + n;
+    int G = n_states >= 4096 ? 8 : (n_states >= 1024 ? 4 : (n_states >= 512 ? 2 : 1));
+    while (G > 1 && plan_lds_doubles(G, n, C) * 8 > 48 * 1024) G >>= 1;
+    const size_t lds = plan_lds_doubles(G, n, C) * 8;
+    AV_REQUIRE(lds <= 64 * 1024, AV_EINVAL, "av_planner_plan: configuration needs %zu B of LDS", lds);
+    const int grid = (n_states + G - 1) / G;
+    hipStream_t st = as_stream(stream);
+#define AV_PLAN_LAUNCH(GG)                                                                                        \
+    hipLaunchKernelGGL(planner_kernel<GG>, dim3(grid), dim3(256), lds, st, p, n_states, state, ref_path, n_ref,  \
+                       obstacles, n_obs, waypoints, cost, order)
+    switch (G) {
+        case 8: AV_PLAN_LAUNCH(8); break;
+        case 4: AV_PLAN_LAUNCH(4); break;
+        case 2: AV_PLAN_LAUNCH(2); break;
+        default: AV_PLAN_LAUNCH(1); break;
+    }
+#undef AV_PLAN_LAUNCH
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // extern "C"

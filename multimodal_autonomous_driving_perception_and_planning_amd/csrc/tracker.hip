@@ -1,0 +1,329 @@
+// K1-K3: batched IoU tracker.
+//
+// Reference: MultiObjectTracker (src/tracking/multi_object_tracker.py)
+//   _compute_iou :84-105   integer areas, one float64 divide, 0.0 when boxes do not overlap
+//   _associate   :113-164  greedy: take the global arg-max of the T x D IoU matrix (first in
+//                          row-major order on ties, :150) until max < iou_threshold (:147)
+//   update       :166-241  matched / missed / born / dead / confirmed
+//
+// Mapping: one workgroup per video stream, one thread per track row (blockDim = tcap), frames of
+// the window processed sequentially.  The table lives in registers for the whole window; rows are
+// kept in ascending-id order (== the reference's dict insertion order) and compacted through LDS
+// only on frames where a track dies.  The T x D matrix is never materialised: each row caches
+// its best unused detection (lowest column on ties) and recomputes it only when that column is
+// taken, which reproduces the reference's pick order exactly.  The float64 quotient inter/union is
+// formed from exact integers, so every comparison sees the bits NumPy sees.
+#include "common.h"
+
+namespace {
+
+constexpr int HDR_INTS = 16;
+
+__host__ __device__ inline size_t state_bytes(int tcap, int L) {
+    return (size_t)HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row) + (size_t)tcap * L * 4 * sizeof(double);
+}
+
+struct Row {
+    int id, x1, y1, x2, y2, cls, age, hits, misses, slot, hlen;
+    double conf;
+};
+
+__device__ __forceinline__ double iou_f64(int ax1, int ay1, int ax2, int ay2, int bx1, int by1, int bx2, int by2) {
+    const int xi1 = ax1 > bx1 ? ax1 : bx1, yi1 = ay1 > by1 ? ay1 : by1;
+    const int xi2 = ax2 < bx2 ? ax2 : bx2, yi2 = ay2 < by2 ? ay2 : by2;
+    if (xi2 <= xi1 || yi2 <= yi1) return 0.0;
+    const long long inter = (long long)(xi2 - xi1) * (long long)(yi2 - yi1);
+    const long long a1 = (long long)(ax2 - ax1) * (long long)(ay2 - ay1);
+    const long long a2 = (long long)(bx2 - bx1) * (long long)(by2 - by1);
+    const long long uni = a1 + a2 - inter;
+    return uni > 0 ? (double)inter / (double)uni : 0.0;
+}
+
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
+    for (int i = 0; i < n; ++i) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+
+struct Shared {
+    int dbox[64][4];
+    int dcls[64];
+    double dconf[64];
+    int d2t[64];
+    double w_iou[16];
+    int w_row[16];
+    int w_col[16];
+    int w_cnt[16];
+    unsigned slot_bits[32];
+    int birth_slot[64];
+    int misc[4];
+};
+
+template <bool MULTIWAVE>
+__global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
+                               const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
+                               const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
+                               av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
+                               int32_t* __restrict__ det2trk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Shared& sh = *reinterpret_cast<Shared*>(smem);
+    av_track_row* stage = reinterpret_cast<av_track_row*>(smem + ((sizeof(Shared) + 63) & ~size_t(63)));
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int nwaves = (tcap + 63) >> 6;
+    const int L = cfg.trajectory_length;
+
+    unsigned char* st = state_all + (size_t)s * state_bytes(tcap, L);
+    int* hdr = reinterpret_cast<int*>(st);
+    av_track_row* rows = reinterpret_cast<av_track_row*>(st + HDR_INTS * 4);
+    double* hist = reinterpret_cast<double*>(st + HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row));
+
+    int T = hdr[0], next_id = hdr[1], frame_count = hdr[2], status = hdr[3];
+    Row r{};
+    if (tid < T) {
+        const av_track_row g = rows[tid];
+        r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
+        r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+        r.conf = g.conf;
+    }
+    if (tid < 32) sh.slot_bits[tid] = 0;
+    __syncthreads();
+    if (tid < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
+    __syncthreads();
+
+    for (int f = 0; f < n_frames; ++f) {
+        const size_t sf = (size_t)s * n_frames + f;
+        int nd = det_n[sf];
+        nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
+        frame_count += 1;
+        if (tid < dcap) {
+            sh.d2t[tid] = -1;
+            if (tid < nd) {
+                const int4 b = reinterpret_cast<const int4*>(det_box)[sf * dcap + tid];
+                sh.dbox[tid][0] = b.x, sh.dbox[tid][1] = b.y, sh.dbox[tid][2] = b.z, sh.dbox[tid][3] = b.w;
+                sh.dcls[tid] = det_cls[sf * dcap + tid];
+                sh.dconf[tid] = det_conf[sf * dcap + tid];
+            }
+        }
+        __syncthreads();
+
+        // ---- association (multi_object_tracker.py:113-164) ------------------------------------
+        unsigned long long used = 0;          // columns already taken; identical in every thread
+        int matched_j = -1;
+        const bool active = tid < T;
+        double best = -1.0;
+        int best_j = -1;
+        auto recompute = [&]() {
+            best = -1.0;
+            best_j = -1;
+            for (int j = 0; j < nd; ++j) {
+                if ((used >> j) & 1ull) continue;
+                const double v = iou_f64(r.x1, r.y1, r.x2, r.y2, sh.dbox[j][0], sh.dbox[j][1], sh.dbox[j][2], sh.dbox[j][3]);
+                if (v > best) best = v, best_j = j;
+            }
+            if (!(best >= cfg.iou_threshold)) best = -1.0, best_j = -1;   // :147  max < thr -> stop
+        };
+        if (active && nd > 0) recompute();
+        if (T > 0 && nd > 0) {
+            const int max_iter = T < nd ? T : nd;
+            for (int it = 0; it < max_iter; ++it) {
+                const double key = (active && matched_j < 0 && best_j >= 0) ? best : -1.0;
+                const double wmax = wave_max(key);
+                const unsigned long long bal = __ballot(key == wmax && key >= 0.0);
+                int win_row = -1, win_col = -1;
+                double win_iou = -1.0;
+                if (bal) {
+                    const int leader = __ffsll((long long)bal) - 1;
+                    win_row = (wid << 6) + leader;
+                    win_col = __shfl(best_j, leader, 64);
+                    win_iou = wmax;
+                }
+                if (MULTIWAVE) {
+                    if (lane == 0) sh.w_iou[wid] = win_iou, sh.w_row[wid] = win_row, sh.w_col[wid] = win_col;
+                    __syncthreads();
+                    win_iou = -1.0, win_row = -1, win_col = -1;
+                    for (int w = 0; w < nwaves; ++w)          // ascending wave == ascending row
+                        if (sh.w_iou[w] > win_iou) win_iou = sh.w_iou[w], win_row = sh.w_row[w], win_col = sh.w_col[w];
+                    __syncthreads();
+                }
+                if (win_row < 0) break;
+                used |= 1ull << win_col;
+                if (tid == win_row) matched_j = win_col;
+                else if (active && matched_j < 0 && best_j == win_col) recompute();
+            }
+        }
+
+        // ---- matched / missed (:182-211) ---------------------------------------------------------
+        if (active) {
+            if (matched_j >= 0) {
+                const int nx1 = sh.dbox[matched_j][0], ny1 = sh.dbox[matched_j][1];
+                const int nx2 = sh.dbox[matched_j][2], ny2 = sh.dbox[matched_j][3];
+                const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
+                const double ncx = (double)(nx1 + nx2) / 2.0, ncy = (double)(ny1 + ny2) / 2.0;
+                r.x1 = nx1, r.y1 = ny1, r.x2 = nx2, r.y2 = ny2;
+                r.conf = sh.dconf[matched_j];
+                r.age += 1, r.hits += 1, r.misses = 0;
+                double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + (r.hlen % L)) * 4);
+                *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                r.hlen += 1;
+                sh.d2t[matched_j] = r.id;
+            } else {
+                r.age += 1, r.misses += 1;
+            }
+        }
+
+        // ---- births (:214-225) ------------------------------------------------------------------
+        const unsigned long long dmask = nd >= 64 ? ~0ull : ((1ull << nd) - 1ull);
+        const unsigned long long unm = ~used & dmask;
+        const int nb = __popcll(unm);
+        int nb_fit = nb;
+        if (T + nb > tcap) nb_fit = tcap - T, status |= 1;
+        if (nb > 0) {
+            // rank of each free history slot; the b-th birth takes the b-th free slot
+            {
+                const unsigned word = sh.slot_bits[tid >> 5];
+                const bool is_free = !((word >> (tid & 31)) & 1u);
+                int below = __popc(~word & ((1u << (tid & 31)) - 1u));
+                for (int w = 0; w < (tid >> 5); ++w) below += 32 - __popc(sh.slot_bits[w]);
+                if (is_free && below < nb_fit) sh.birth_slot[below] = tid;
+            }
+            if (tid < nd && ((unm >> tid) & 1ull)) {
+                const int b = __popcll(unm & ((1ull << tid) - 1ull));
+                sh.d2t[tid] = next_id + b;
+            }
+            __syncthreads();
+            if (tid >= T && tid < T + nb_fit) {
+                const int b = tid - T;
+                const int j = nth_set_bit(unm, b);
+                r.id = next_id + b;
+                r.x1 = sh.dbox[j][0], r.y1 = sh.dbox[j][1], r.x2 = sh.dbox[j][2], r.y2 = sh.dbox[j][3];
+                r.cls = sh.dcls[j];
+                r.conf = sh.dconf[j];
+                r.age = 0, r.hits = 1, r.misses = 0;
+                r.slot = sh.birth_slot[b];
+                r.hlen = 1;
+                double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
+                *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
+                atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
+            }
+            next_id += nb;
+            T += nb_fit;
+        }
+
+        // ---- deaths (:228-233): order-preserving compaction --------------------------------------
+        const bool live_row = tid < T;
+        const bool dead = live_row && (r.misses > cfg.max_age);
+        const int any_dead = __syncthreads_or(dead ? 1 : 0);
+        if (any_dead) {
+            const bool keep = live_row && !dead;
+            const unsigned long long kb = __ballot(keep);
+            int pos = __popcll(kb & ((1ull << lane) - 1ull));
+            int total = __popcll(kb);
+            if (MULTIWAVE) {
+                if (lane == 0) sh.w_cnt[wid] = total;
+                __syncthreads();
+                total = 0;
+                for (int w = 0; w < nwaves; ++w) {
+                    if (w < wid) pos += sh.w_cnt[w];
+                    total += sh.w_cnt[w];
+                }
+            }
+            if (dead) atomicAnd(&sh.slot_bits[r.slot >> 5], ~(1u << (r.slot & 31)));
+            if (keep) {
+                av_track_row g;
+                g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+                g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+                g.flags = 0, g.conf = r.conf, g.reserved = 0.0;
+                stage[pos] = g;
+            }
+            __syncthreads();
+            T = total;
+            if (tid < T) {
+                const av_track_row g = stage[tid];
+                r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
+                r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+                r.conf = g.conf;
+            }
+        }
+
+        // ---- per-frame outputs --------------------------------------------------------------------
+        if (snap) {
+            if (tid < T) {
+                av_track_row g;
+                g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+                g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+                g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
+                g.conf = r.conf, g.reserved = 0.0;
+                snap[sf * tcap + tid] = g;
+            }
+            if (tid == 0) snap_n[sf] = T;
+        }
+        if (det2trk && tid < dcap) det2trk[sf * dcap + tid] = sh.d2t[tid];
+        __syncthreads();          // sh.d* are rewritten by the next frame
+    }
+
+    // ---- persist ----------------------------------------------------------------------------------
+    if (tid < T) {
+        av_track_row g;
+        g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+        g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+        g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
+        g.conf = r.conf, g.reserved = 0.0;
+        rows[tid] = g;
+    }
+    if (tid == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
+}
+
+__global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, unsigned char* state) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    int* hdr = reinterpret_cast<int*>(state + (size_t)s * bytes_per_stream);
+    for (int i = 0; i < HDR_INTS; ++i) hdr[i] = 0;
+    hdr[1] = 1;     // next_id starts at 1 (multi_object_tracker.py:81)
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t av_tracker_state_bytes(int tcap, int trajectory_length) {
+    if (tcap <= 0 || trajectory_length <= 0) return 0;
+    return state_bytes(tcap, trajectory_length);
+}
+
+int av_tracker_reset(av_ctx* ctx, av_stream_t stream, int n_streams, int tcap, int trajectory_length, void* state) {
+    AV_REQUIRE(ctx && state, AV_EINVAL, "av_tracker_reset: null argument");
+    AV_REQUIRE(n_streams > 0 && tcap > 0 && trajectory_length > 0, AV_EINVAL, "av_tracker_reset: bad sizes");
+    hipLaunchKernelGGL(tracker_reset_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, as_stream(stream), n_streams,
+                       state_bytes(tcap, trajectory_length), (unsigned char*)state);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg, int n_streams, int n_frames,
+                      int dcap, const int32_t* det_n, const int32_t* det_box, const int32_t* det_cls,
+                      const double* det_conf, int tcap, void* state, av_track_row* snap, int32_t* snap_n,
+                      int32_t* det2trk) {
+    AV_REQUIRE(ctx && cfg && det_n && det_box && det_cls && det_conf && state, AV_EINVAL,
+               "av_tracker_update: null argument");
+    AV_REQUIRE(n_streams > 0 && n_frames > 0, AV_EINVAL, "av_tracker_update: n_streams/n_frames must be > 0");
+    AV_REQUIRE(tcap >= 64 && tcap <= 1024 && (tcap % 64) == 0, AV_EINVAL,
+               "av_tracker_update: tcap %d must be a multiple of 64 in [64,1024]", tcap);
+    AV_REQUIRE(dcap >= 1 && dcap <= 64, AV_EINVAL, "av_tracker_update: dcap %d not in [1,64]", dcap);
+    AV_REQUIRE(cfg->trajectory_length >= 1, AV_EINVAL, "av_tracker_update: trajectory_length must be >= 1");
+    AV_REQUIRE(cfg->iou_threshold >= 0.0, AV_EINVAL,
+               "av_tracker_update: iou_threshold < 0 never terminates in the reference either");
+    AV_REQUIRE((snap == nullptr) == (snap_n == nullptr), AV_EINVAL, "av_tracker_update: snap and snap_n go together");
+    const size_t lds = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
+    if (tcap == 64)
+        hipLaunchKernelGGL(tracker_kernel<false>, dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,
+                           dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk);
+    else
+        hipLaunchKernelGGL(tracker_kernel<true>, dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,
+                           dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // extern "C"

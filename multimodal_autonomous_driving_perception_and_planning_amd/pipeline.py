@@ -1,0 +1,188 @@
+"""Batched hot loop: S independent video streams x W frames per launch, all state resident in HBM.
+
+This is the host-side driver of the simulated-detection configuration (BASELINE configs 2/4/5):
+
+    detect (av_simdet_generate) -> track (av_tracker_update)          side stream
+                                   Kalman (av_kf_step) -> plan (av_planner_plan)   main stream
+
+in the reference's per-frame call order (demo.py:97-120).  Tracker and Kalman/planner are
+independent (the planner never consumes tracks), so they run as two branches
+of one fork/join, optionally captured into a hipGraph.  PyTorch only provides device memory and
+the stream; every kernel is in libavhot.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+class HotLoop:
+    def __init__(self, n_streams=1, window=1, h=720, w=1280, tcap=64, dcap=8, device=0,
+                 tracker_kw=None, kf_kw=None, planner_kw=None, keep_waypoints=True, keep_snapshots=True,
+                 ctx=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HotLoop needs a HIP device; this package has no CPU path")
+        self.S, self.W, self.h, self.w, self.tcap, self.dcap = n_streams, window, h, w, tcap, dcap
+        self.dev = torch.device("cuda", device)
+        self.ctx = ctx or nat.Context(device)
+        self.L = nat.lib()
+        tk = dict(iou_threshold=0.3, max_age=30, min_hits=3, trajectory_length=50)
+        tk.update(tracker_kw or {})
+        self.tcfg = nat.TrackerCfg(**tk)
+        kk = dict(dt=0.033, process_noise=0.1, measurement_noise=1.0)
+        kk.update(kf_kw or {})
+        self.kcfg = nat.KfCfg(**kk)
+        pk = dict(planning_horizon=5.0, dt=0.1, num_samples=7, w_lateral=1.0, w_velocity=0.5,
+                  w_acceleration=0.3, w_curvature=0.4)
+        pk.update(planner_kw or {})
+        self.pcfg = nat.PlannerCfg(reserved=0, **pk)
+        nat.check(self.L.av_planner_configure(self.ctx.handle, C.byref(self.pcfg)))
+        n, c = C.c_int(), C.c_int()
+        nat.check(self.L.av_planner_dims(self.ctx.handle, C.byref(n), C.byref(c)))
+        self.n_points, self.n_cand = n.value, c.value
+
+        S, W, d = n_streams, window, self.dev
+        i32, f64 = torch.int32, torch.float64
+        self.frame_count = torch.zeros(S, dtype=i32, device=d)
+        self.det_n = torch.zeros(S, W, dtype=i32, device=d)
+        self.det_box = torch.zeros(S, W, dcap, 4, dtype=i32, device=d)
+        self.det_cls = torch.zeros(S, W, dcap, dtype=i32, device=d)
+        self.det_conf = torch.zeros(S, W, dcap, dtype=f64, device=d)
+        self.det_status = torch.zeros(S, dtype=i32, device=d)
+        self.trk_bytes = int(self.L.av_tracker_state_bytes(tcap, self.tcfg.trajectory_length))
+        self.trk_state = torch.zeros(S, self.trk_bytes, dtype=torch.uint8, device=d)
+        self.keep_snapshots = keep_snapshots
+        self.snap = torch.zeros(S, W, tcap, nat.TRACK_ROW_BYTES, dtype=torch.uint8, device=d) if keep_snapshots else None
+        self.snap_n = torch.zeros(S, W, dtype=i32, device=d) if keep_snapshots else None
+        self.det2trk = torch.zeros(S, W, dcap, dtype=i32, device=d)
+        self.z = torch.zeros(S, W, 4, dtype=f64, device=d)
+        self.kf_state = torch.zeros(S, nat.KF_STATE_DOUBLES, dtype=f64, device=d)
+        self.vstate = torch.zeros(S, W, nat.VSTATE_DOUBLES, dtype=f64, device=d)
+        self.plan_state = torch.zeros(S, W, 4, dtype=f64, device=d)
+        self.keep_waypoints = keep_waypoints
+        self.wp = (torch.zeros(S * W, self.n_cand, self.n_points, nat.WP_DOUBLES, dtype=f64, device=d)
+                   if keep_waypoints else None)
+        self.cost = torch.zeros(S * W, self.n_cand, dtype=f64, device=d)
+        self.order = torch.zeros(S * W, self.n_cand, dtype=i32, device=d)
+        self.stream = torch.cuda.Stream(device=d)
+        self.graph_id = None
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def reset(self, frame_offsets=None):
+        """Resets every stream (tracker.reset(), state_estimator.reset(), detector.reset())."""
+        h, L = self.ctx.handle, self.L
+        nat.check(L.av_tracker_reset(h, self._s, self.S, self.tcap, self.tcfg.trajectory_length, nat.ptr(self.trk_state)))
+        nat.check(L.av_kf_reset(h, self._s, self.S, nat.ptr(self.kf_state)))
+        with torch.cuda.stream(self.stream):
+            if frame_offsets is None:
+                self.frame_count.zero_()
+            else:
+                self.frame_count.copy_(torch.as_tensor(np.asarray(frame_offsets, np.int32)), non_blocking=False)
+        self.stream.synchronize()
+
+    def load_measurements(self, z):
+        """z: float64 [S, W, 4] ego measurements for the next window (host array)."""
+        with torch.cuda.stream(self.stream):
+            self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
+        self.stream.synchronize()
+
+    # ---- individual stages (enqueue only) --------------------------------------------------------
+    def enqueue_detect(self, stream=None):
+        nat.check(self.L.av_simdet_generate(self.ctx.handle, stream or self._s, self.S, self.W, self.h, self.w,
+                                            self.dcap, nat.ptr(self.frame_count), nat.ptr(self.det_n),
+                                            nat.ptr(self.det_box), nat.ptr(self.det_cls), nat.ptr(self.det_conf),
+                                            nat.ptr(self.det_status)))
+
+    def enqueue_track(self, stream=None):
+        nat.check(self.L.av_tracker_update(self.ctx.handle, stream or self._s, C.byref(self.tcfg), self.S, self.W,
+                                           self.dcap, nat.ptr(self.det_n), nat.ptr(self.det_box),
+                                           nat.ptr(self.det_cls), nat.ptr(self.det_conf), self.tcap,
+                                           nat.ptr(self.trk_state), nat.ptr(self.snap), nat.ptr(self.snap_n),
+                                           nat.ptr(self.det2trk)))
+
+    def enqueue_kf(self, stream=None):
+        nat.check(self.L.av_kf_step(self.ctx.handle, stream or self._s, C.byref(self.kcfg), self.S, self.W,
+                                    nat.ptr(self.z), None, nat.ptr(self.kf_state), nat.ptr(self.vstate),
+                                    nat.ptr(self.plan_state)))
+
+    def enqueue_plan(self, stream=None):
+        nat.check(self.L.av_planner_plan(self.ctx.handle, stream or self._s, self.S * self.W,
+                                         nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),
+                                         nat.ptr(self.cost), nat.ptr(self.order)))
+
+    def enqueue_step(self):
+        """One window of the whole loop: detect; fork{track} || {kf; plan}; join."""
+        h, L, s = self.ctx.handle, self.L, self._s
+        self.enqueue_detect()
+        nat.check(L.av_fork(h, s))
+        self.enqueue_track(self.ctx.side_stream)
+        self.enqueue_kf()
+        self.enqueue_plan()
+        nat.check(L.av_join(h, s))
+
+    def capture(self):
+        """Capture enqueue_step() into a hipGraph (replayed by step(graph=True))."""
+        gid = C.c_int(-1)
+        nat.check(self.L.av_graph_begin(self.ctx.handle, self._s))
+        try:
+            self.enqueue_step()
+        finally:
+            nat.check(self.L.av_graph_end(self.ctx.handle, self._s, C.byref(gid)))
+        self.graph_id = gid.value
+        return self.graph_id
+
+    def step(self, graph=False, sync=False):
+        if graph:
+            if self.graph_id is None:
+                self.capture()
+            nat.check(self.L.av_graph_launch(self.ctx.handle, self.graph_id, self._s))
+        else:
+            self.enqueue_step()
+        if sync:
+            self.stream.synchronize()
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    # ---- host views of the last window -------------------------------------------------------------
+    def snapshots(self):
+        """-> (rows structured array [S,W,tcap], n [S,W]) for the last window."""
+        self.stream.synchronize()
+        raw = self.snap.cpu().numpy()
+        rows = raw.view(np.dtype(nat.TRACK_ROW_FIELDS)).reshape(self.S, self.W, self.tcap)
+        return rows, self.snap_n.cpu().numpy()
+
+    def tracker_tables(self):
+        """Persistent per-stream state: (hdr int32[S,16], rows [S,tcap], hist float64[S,tcap,L,4])."""
+        self.stream.synchronize()
+        raw = self.trk_state.cpu().numpy()
+        L = self.tcfg.trajectory_length
+        hdr = raw[:, :nat.TRACKER_HDR_BYTES].copy().view(np.int32)
+        ro = nat.TRACKER_HDR_BYTES
+        rows = raw[:, ro:ro + self.tcap * 64].copy().view(np.dtype(nat.TRACK_ROW_FIELDS)).reshape(self.S, self.tcap)
+        hist = raw[:, ro + self.tcap * 64:].copy().view(np.float64).reshape(self.S, self.tcap, L, 4)
+        return hdr, rows, hist
+
+    def results(self):
+        self.stream.synchronize()
+        out = dict(det_n=self.det_n.cpu().numpy(), det_box=self.det_box.cpu().numpy(),
+                   det_cls=self.det_cls.cpu().numpy(), det_conf=self.det_conf.cpu().numpy(),
+                   det2trk=self.det2trk.cpu().numpy(), vstate=self.vstate.cpu().numpy(),
+                   cost=self.cost.cpu().numpy().reshape(self.S, self.W, self.n_cand),
+                   order=self.order.cpu().numpy().reshape(self.S, self.W, self.n_cand))
+        if self.keep_waypoints:
+            out["wp"] = self.wp.cpu().numpy().reshape(self.S, self.W, self.n_cand, self.n_points, 6)
+        return out
+
+    # algorithmic HBM bytes of one planner launch: per start state
+    # 32 B read + C*n*48 B waypoints + C*8 B costs + C*4 B order
+    def planner_bytes_per_state(self):
+        c, n = self.n_cand, self.n_points
+        return 32 + c * n * 48 + c * 8 + c * 4
