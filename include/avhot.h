@@ -186,6 +186,17 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
                     const double* ref_path, int n_ref, const double* obstacles, int n_obs,
                     double* waypoints, double* cost, int32_t* order);
 
+/* generate_polynomial_trajectory for arbitrary (lateral offset, target speed) pairs (:126-204).
+ *   state [n_traj][4], end_lateral_offset [n_traj], target_velocity [n_traj] -> waypoints [n_traj][n][6] */
+int av_planner_generate(av_ctx* ctx, av_stream_t stream, int n_traj, const double* state,
+                        const double* end_lateral_offset, const double* target_velocity,
+                        double* waypoints);
+/* evaluate_trajectory_cost for caller-supplied trajectories of any length (:206-262), accumulated
+ * strictly left to right like the reference.  waypoints [n_traj][n_wp][6]; n_wp == 0 -> +inf (:218). */
+int av_planner_evaluate(av_ctx* ctx, av_stream_t stream, int n_traj, int n_wp, const double* waypoints,
+                        const double* ref_path, int n_ref, const double* obstacles, int n_obs,
+                        double* cost);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ _SIGS = [
     ("av_planner_configure", C.c_int, [vp, C.POINTER(PlannerCfg)]),
     ("av_planner_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("av_planner_plan", C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
+    ("av_planner_generate", C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
+    ("av_planner_evaluate", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
 ]
 
 # entry points added by later translation units; bound when present in the header list below

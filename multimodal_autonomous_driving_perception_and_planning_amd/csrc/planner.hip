@@ -194,9 +194,145 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
     }
 }
 
+// generate_polynomial_trajectory for one arbitrary (df, vt): one wave per trajectory.
+__global__ void __launch_bounds__(64) planner_generate_kernel(PlanParams p, int n_traj, const double* __restrict__ state,
+                                                              const double* __restrict__ dfs,
+                                                              const double* __restrict__ vts, double* __restrict__ wp) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = p.n, lane = threadIdx.x, j = blockIdx.x;
+    if (j >= n_traj) return;
+    double* vs = sm;                 // [n][2]
+    double* stage = sm + 2 * n;      // [n][6]
+    const double x0 = state[4 * j], y0 = state[4 * j + 1], h0 = state[4 * j + 2], v0 = state[4 * j + 3];
+    const double df = dfs[j], vt = vts[j];
+    if (lane == 0) {
+        const double dv = vt - v0;
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double v = v0 + dv * p.alpha[i];
+            if (i > 0) s = s + v * p.dt;
+            vs[2 * i] = v, vs[2 * i + 1] = s;
+        }
+    }
+    wave_lds_fence();
+    const double hp2 = h0 + 1.5707963267948966;
+    const double cs = cos(h0), sn = sin(h0), c2 = cos(hp2), s2 = sin(hp2);
+    for (int i = lane; i < n; i += 64) {
+        const double v = vs[2 * i], s = vs[2 * i + 1];
+        const double d = df * p.q[i];
+        double x = x0 + s * cs, y = y0 + s * sn;
+        x = x + d * c2, y = y + d * s2;
+        double hd = 0.0;
+        if (i < n - 1) {
+            const double s1 = vs[2 * i + 3], d1 = df * p.q[i + 1];
+            double x1 = x0 + s1 * cs, y1 = y0 + s1 * sn;
+            x1 = x1 + d1 * c2, y1 = y1 + d1 * s2;
+            hd = atan2(y1 - y, x1 - x);
+        }
+        double* w = stage + (size_t)i * 6;
+        w[0] = x, w[1] = y, w[2] = hd, w[3] = v, w[4] = p.t[i], w[5] = 0.0;
+    }
+    wave_lds_fence();
+    for (int i = lane; i < n; i += 64)
+        if (i > 0 && i < n - 1) {
+            double* w = stage + (size_t)i * 6;
+            w[5] = (w[2] - stage[(size_t)(i - 1) * 6 + 2]) / (w[3] * p.dt + 1e-6);
+        }
+    wave_lds_fence();
+    if (lane == 0) stage[(size_t)(n - 1) * 6 + 2] = n > 1 ? stage[(size_t)(n - 2) * 6 + 2] : h0;
+    wave_lds_fence();
+    double* dst = wp + (size_t)j * n * 6;
+    for (int q = lane; q < n * 6; q += 64) dst[q] = stage[q];
+}
+
+// evaluate_trajectory_cost for an arbitrary trajectory, strictly in the reference's accumulation order
+// (one thread per trajectory; this is a utility entry, the hot path is planner_kernel).
+__global__ void planner_evaluate_kernel(PlanParams p, int n_traj, int n_wp, const double* __restrict__ wp,
+                                        const double* __restrict__ ref, int n_ref, const double* __restrict__ obs,
+                                        int n_obs, double* __restrict__ cost) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_traj) return;
+    if (n_wp == 0) {
+        cost[j] = INFINITY;
+        return;
+    }
+    const double* w = wp + (size_t)j * n_wp * 6;
+    double c = 0.0;
+    if (n_ref > 0)
+        for (int i = 0; i < n_wp; ++i) {
+            double md = INFINITY;
+            for (int r = 0; r < n_ref; ++r) {
+                const double dx = ref[2 * r] - w[6 * i], dy = ref[2 * r + 1] - w[6 * i + 1];
+                const double dd = sqrt(dx * dx + dy * dy);
+                md = dd < md ? dd : md;
+            }
+            c = c + p.w_lat * (md * md);
+        }
+    for (int i = 0; i < n_wp; ++i) {
+        const double e = w[6 * i + 3] - 10.0;
+        c = c + p.w_vel * (e * e);
+    }
+    for (int i = 1; i < n_wp; ++i) {
+        const double dtt = w[6 * i + 4] - w[6 * (i - 1) + 4];
+        if (dtt > 0.0) {
+            const double a = (w[6 * i + 3] - w[6 * (i - 1) + 3]) / dtt;
+            c = c + p.w_acc * (a * a);
+        }
+    }
+    for (int i = 0; i < n_wp; ++i) c = c + p.w_curv * (w[6 * i + 5] * w[6 * i + 5]);
+    for (int q = 0; q < n_obs; ++q) {
+        const double ox = obs[3 * q], oy = obs[3 * q + 1], rad = obs[3 * q + 2];
+        for (int i = 0; i < n_wp; ++i) {
+            const double ex = w[6 * i] - ox, ey = w[6 * i + 1] - oy;
+            const double dist = sqrt(ex * ex + ey * ey);
+            if (dist < rad * 2.0) c = c + 1000.0 * (rad * 2.0 - dist);
+            else if (dist < rad * 4.0) c = c + 10.0 / (dist - rad + 0.1);
+        }
+    }
+    cost[j] = c;
+}
+
 }  // namespace
 
+static void fill_params(const av_ctx* ctx, PlanParams& p) {
+    const int n = ctx->n_points;
+    p.n = n, p.n_lat = ctx->n_lat, p.C = ctx->n_cand;
+    p.dt = ctx->pcfg.dt, p.H = ctx->pcfg.planning_horizon;
+    p.w_lat = ctx->pcfg.w_lateral, p.w_vel = ctx->pcfg.w_velocity, p.w_acc = ctx->pcfg.w_acceleration;
+    p.w_curv = ctx->pcfg.w_curvature;
+    p.t = ctx->d_ptab, p.alpha = p.t + n, p.q = p.alpha + n, p.dtd = p.q + n, p.lat = p.dtd + n;
+}
+
 extern "C" {
+
+int av_planner_generate(av_ctx* ctx, av_stream_t stream, int n_traj, const double* state,
+                        const double* end_lateral_offset, const double* target_velocity, double* waypoints) {
+    AV_REQUIRE(ctx && state && end_lateral_offset && target_velocity && waypoints, AV_EINVAL,
+               "av_planner_generate: null argument");
+    AV_REQUIRE(ctx->planner_ready, AV_ESTATE, "av_planner_generate: call av_planner_configure first");
+    AV_REQUIRE(n_traj > 0, AV_EINVAL, "av_planner_generate: n_traj must be > 0");
+    PlanParams p;
+    fill_params(ctx, p);
+    hipLaunchKernelGGL(planner_generate_kernel, dim3(n_traj), dim3(64), (size_t)p.n * 8 * 8, as_stream(stream), p,
+                       n_traj, state, end_lateral_offset, target_velocity, waypoints);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_planner_evaluate(av_ctx* ctx, av_stream_t stream, int n_traj, int n_wp, const double* waypoints,
+                        const double* ref_path, int n_ref, const double* obstacles, int n_obs, double* cost) {
+    AV_REQUIRE(ctx && cost && (waypoints || n_wp == 0), AV_EINVAL, "av_planner_evaluate: null argument");
+    AV_REQUIRE(ctx->planner_ready, AV_ESTATE, "av_planner_evaluate: call av_planner_configure first");
+    AV_REQUIRE(n_traj > 0 && n_wp >= 0, AV_EINVAL, "av_planner_evaluate: bad sizes");
+    AV_REQUIRE(n_ref >= 0 && n_obs >= 0 && (n_ref == 0 || ref_path) && (n_obs == 0 || obstacles), AV_EINVAL,
+               "av_planner_evaluate: ref_path/obstacles pointer missing");
+    PlanParams p;
+    fill_params(ctx, p);
+    hipLaunchKernelGGL(planner_evaluate_kernel, dim3((n_traj + 63) / 64), dim3(64), 0, as_stream(stream), p, n_traj,
+                       n_wp, waypoints, ref_path, n_ref, obstacles, n_obs, cost);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
 
 int av_planner_configure(av_ctx* ctx, const av_planner_cfg* cfg) {
     AV_REQUIRE(ctx && cfg, AV_EINVAL, "av_planner_configure: null argument");
@@ -261,11 +397,7 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
     AV_REQUIRE(n_ref != 1, AV_EINVAL, "av_planner_plan: a reference path needs >= 2 points (set_reference_path ignores shorter)");
     const int n = ctx->n_points, C = ctx->n_cand;
     PlanParams p;
-    p.n = n, p.n_lat = ctx->n_lat, p.C = C;
-    p.dt = ctx->pcfg.dt, p.H = ctx->pcfg.planning_horizon;
-    p.w_lat = ctx->pcfg.w_lateral, p.w_vel = ctx->pcfg.w_velocity, p.w_acc = ctx->pcfg.w_acceleration;
-    p.w_curv = ctx->pcfg.w_curvature;
-    p.t = ctx->d_ptab, p.alpha = p.t + n, p.q = p.alpha + n, p.dtd = p.q + n, p.lat = p.dtd + n;
+    fill_params(ctx, p);
     int G = n_states >= 4096 ? 8 : (n_states >= 1024 ? 4 : (n_states >= 512 ? 2 : 1));
     while (G > 1 && plan_lds_doubles(G, n, C) * 8 > 48 * 1024) G >>= 1;
     const size_t lds = plan_lds_doubles(G, n, C) * 8;

@@ -1,0 +1,109 @@
+"""ObjectDetector -- drop-in surface of src/perception/detector.py over libavhot.so.
+
+mode="simulated": the detections of frame k are produced on the GPU by av_simdet_generate, which
+re-derives NumPy's legacy MT19937 stream the reference seeds with frame_count % 1000
+(detector.py:125-169).  Unlike the reference, the process-global np.random state is left alone.
+mode="yolo": a YOLOv8n-topology network run by the library's MFMA convolution path (see yolo.py);
+like the reference (detector.py:79-84) it silently falls back to "simulated" when the model cannot
+be set up.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .._dev import Dev
+
+
+@dataclass
+class Detection:
+    """One detected object (detector.py:14-26)."""
+    bbox: Tuple[int, int, int, int]
+    class_id: int
+    class_name: str
+    confidence: float
+    center: Tuple[float, float] = None
+
+    def __post_init__(self):
+        if self.center is None:
+            x1, y1, x2, y2 = self.bbox
+            self.center = ((x1 + x2) / 2, (y1 + y2) / 2)
+
+
+class ObjectDetector:
+    CLASSES = {0: "car", 1: "truck", 2: "pedestrian", 3: "cyclist", 4: "motorcycle", 5: "bus",
+               6: "traffic_light", 7: "stop_sign"}
+    CLASS_COLORS = {0: (0, 255, 0), 1: (0, 165, 255), 2: (0, 0, 255), 3: (255, 255, 0), 4: (255, 0, 255),
+                    5: (0, 255, 255), 6: (128, 0, 128), 7: (0, 128, 255)}
+    DCAP = 8
+
+    def __init__(self, mode: str = "simulated", model_path: Optional[str] = None, device: int = 0):
+        self.mode = mode
+        self.model = None
+        self.frame_count = 0
+        self._dev = Dev(device)
+        d = self._dev
+        self._fc = d.zeros(1, torch.int32)
+        self._n = d.zeros((1, 1), torch.int32)
+        self._box = d.zeros((1, 1, self.DCAP, 4), torch.int32)
+        self._cls = d.zeros((1, 1, self.DCAP), torch.int32)
+        self._conf = d.zeros((1, 1, self.DCAP), torch.float64)
+        self._status = d.zeros(1, torch.int32)
+        if mode == "yolo" and model_path:
+            self._load_yolo_model(model_path)
+
+    def _load_yolo_model(self, model_path: str):
+        try:
+            from .yolo import YoloV8n
+            self.model = YoloV8n(model_path, device=self._dev.index)
+        except (ImportError, FileNotFoundError) as e:
+            print("YOLO path unavailable (%s). Falling back to simulated mode." % e)
+            self.mode = "simulated"
+
+    def detect(self, frame: np.ndarray) -> List[Detection]:
+        self.frame_count += 1
+        if self.mode == "yolo" and self.model is not None:
+            return self._detect_yolo(frame)
+        return self._detect_simulated(frame)
+
+    def _detect_yolo(self, frame):
+        boxes, conf, cls = self.model.detect(frame)
+        names = self.model.names
+        return [Detection(bbox=tuple(int(v) for v in b), class_id=int(k), class_name=names.get(int(k), "unknown"),
+                          confidence=float(c)) for b, c, k in zip(boxes, conf, cls)]
+
+    def _detect_simulated(self, frame) -> List[Detection]:
+        h, w = frame.shape[:2]
+        d = self._dev
+        self._fc.fill_(self.frame_count - 1)        # kernel generates frame_count = counter + 1
+        nat.check(d.lib.av_simdet_generate(d.ctx.handle, d.stream, 1, 1, int(h), int(w), self.DCAP,
+                                           nat.ptr(self._fc), nat.ptr(self._n), nat.ptr(self._box),
+                                           nat.ptr(self._cls), nat.ptr(self._conf), nat.ptr(self._status)))
+        n = int(self._n.item())
+        box = self._box.cpu().numpy()[0, 0]
+        cls = self._cls.cpu().numpy()[0, 0]
+        conf = self._conf.cpu().numpy()[0, 0]
+        return [Detection(bbox=tuple(int(v) for v in box[i]), class_id=int(cls[i]),
+                          class_name=self.CLASSES[int(cls[i])], confidence=float(conf[i])) for i in range(n)]
+
+    def draw_detections(self, frame: np.ndarray, detections: List[Detection], show_labels: bool = True,
+                        show_confidence: bool = True) -> np.ndarray:
+        """Boxes + labels drawn with OpenCV (display only, not on the hot path)."""
+        import cv2
+        out = frame.copy()
+        for det in detections:
+            x1, y1, x2, y2 = det.bbox
+            color = self.CLASS_COLORS.get(det.class_id, (255, 255, 255))
+            cv2.rectangle(out, (x1, y1), (x2, y2), color, 2)
+            if show_labels:
+                text = det.class_name + (" %.2f" % det.confidence if show_confidence else "")
+                (tw, th), _ = cv2.getTextSize(text, cv2.FONT_HERSHEY_SIMPLEX, 0.5, 1)
+                cv2.rectangle(out, (x1, y1 - th - 10), (x1 + tw + 5, y1), color, -1)
+                cv2.putText(out, text, (x1 + 2, y1 - 5), cv2.FONT_HERSHEY_SIMPLEX, 0.5, (0, 0, 0), 1)
+        return out
+
+    def reset(self):
+        self.frame_count = 0

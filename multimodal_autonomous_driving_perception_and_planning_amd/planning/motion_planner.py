@@ -1,0 +1,195 @@
+"""MotionPlanner -- drop-in surface of src/planning/motion_planner.py over libavhot.so.
+
+plan() is one fused launch (av_planner_plan): all 3*num_samples candidates are generated, costed and
+stably ranked on the GPU; the host only wraps the result in Trajectory/Waypoint objects.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .._dev import Dev
+
+
+@dataclass
+class Waypoint:
+    """One trajectory sample (motion_planner.py:14-22)."""
+    x: float
+    y: float
+    heading: float
+    velocity: float
+    timestamp: float
+    curvature: float = 0.0
+
+
+@dataclass
+class Trajectory:
+    """A planned trajectory (motion_planner.py:25-54).  Compared by value, like the reference's dataclass."""
+    waypoints: List[Waypoint]
+    cost: float = 0.0
+    is_feasible: bool = True
+    trajectory_type: str = "nominal"
+
+    @property
+    def length(self) -> float:
+        if len(self.waypoints) < 2:
+            return 0.0
+        total = 0.0
+        for a, b in zip(self.waypoints[:-1], self.waypoints[1:]):
+            total += np.sqrt((b.x - a.x) ** 2 + (b.y - a.y) ** 2)
+        return total
+
+    @property
+    def duration(self) -> float:
+        if not self.waypoints:
+            return 0.0
+        return self.waypoints[-1].timestamp - self.waypoints[0].timestamp
+
+    def get_positions(self) -> np.ndarray:
+        return np.array([[wp.x, wp.y] for wp in self.waypoints])
+
+
+def _to_waypoints(arr):
+    return [Waypoint(*row) for row in arr.tolist()]
+
+
+class MotionPlanner:
+    def __init__(self, planning_horizon: float = 5.0, dt: float = 0.1, num_samples: int = 7, device: int = 0):
+        self.planning_horizon = planning_horizon
+        self.dt = dt
+        self.num_samples = num_samples
+        self.w_lateral = 1.0
+        self.w_velocity = 0.5
+        self.w_acceleration = 0.3
+        self.w_jerk = 0.2            # unused by the reference's cost as well (motion_planner.py:88)
+        self.w_curvature = 0.4
+        self.reference_trajectory: Optional[Trajectory] = None
+        self._dev = Dev(device)
+        self._sig = None
+        self._ref_dev = None
+
+    # ---- device plumbing --------------------------------------------------------------------------
+    def _configure(self):
+        """(Re)builds the constant tables when a public attribute changed since the last call."""
+        sig = (float(self.planning_horizon), float(self.dt), int(self.num_samples), float(self.w_lateral),
+               float(self.w_velocity), float(self.w_acceleration), float(self.w_curvature))
+        d = self._dev
+        cfg = nat.PlannerCfg(sig[0], sig[1], sig[2], 0, sig[3], sig[4], sig[5], sig[6])
+        # the context's tables are shared by every planner on this device: always re-assert ours
+        if getattr(d.ctx, "_planner_sig", None) != sig:
+            nat.check(d.lib.av_planner_configure(d.ctx.handle, C.byref(cfg)))
+            d.ctx._planner_sig = sig
+        if self._sig != sig:
+            n, c = C.c_int(), C.c_int()
+            nat.check(d.lib.av_planner_dims(d.ctx.handle, C.byref(n), C.byref(c)))
+            self._n, self._c = n.value, c.value
+            self._sig = sig
+            self._lat = np.linspace(-3.5, 3.5, int(self.num_samples))
+
+    def _ref_arrays(self):
+        if not self.reference_trajectory:
+            return None, 0
+        pts = self.reference_trajectory.get_positions()
+        return self._dev.upload(pts, np.float64), len(pts)
+
+    @staticmethod
+    def _obs_arrays(dev, obstacles):
+        if not obstacles:
+            return None, 0
+        o = np.asarray([tuple(x) for x in obstacles], np.float64).reshape(-1, 3)
+        return dev.upload(o, np.float64), len(o)
+
+    # ---- reference surface ----------------------------------------------------------------------------
+    def set_reference_path(self, waypoints: List[Tuple[float, float]]):
+        if len(waypoints) < 2:
+            return
+        pts = [(float(x), float(y)) for x, y in waypoints]
+        wps = []
+        for i, (x, y) in enumerate(pts):
+            if i < len(pts) - 1:
+                hd = np.arctan2(pts[i + 1][1] - y, pts[i + 1][0] - x)
+            else:
+                hd = np.arctan2(y - pts[i - 1][1], x - pts[i - 1][0])
+            wps.append(Waypoint(x=x, y=y, heading=hd, velocity=10.0, timestamp=i * 0.5))
+        self.reference_trajectory = Trajectory(waypoints=wps, trajectory_type="reference")
+
+    def generate_polynomial_trajectory(self, start_state: Tuple[float, float, float, float],
+                                       end_lateral_offset: float, target_velocity: float) -> Trajectory:
+        self._configure()
+        d = self._dev
+        st = d.upload(np.asarray(start_state, np.float64).reshape(1, 4), np.float64)
+        df = d.upload([float(end_lateral_offset)], np.float64)
+        vt = d.upload([float(target_velocity)], np.float64)
+        wp = d.empty((1, self._n, nat.WP_DOUBLES), torch.float64)
+        nat.check(d.lib.av_planner_generate(d.ctx.handle, d.stream, 1, nat.ptr(st), nat.ptr(df), nat.ptr(vt), nat.ptr(wp)))
+        return Trajectory(waypoints=_to_waypoints(wp.cpu().numpy()[0]))
+
+    def evaluate_trajectory_cost(self, trajectory: Trajectory,
+                                 obstacles: Optional[List[Tuple[float, float, float]]] = None) -> float:
+        if not trajectory.waypoints:
+            return float("inf")
+        self._configure()
+        d = self._dev
+        arr = np.array([[w.x, w.y, w.heading, w.velocity, w.timestamp, w.curvature] for w in trajectory.waypoints],
+                       np.float64)
+        wp = d.upload(arr.reshape(1, -1, 6), np.float64)
+        ref, nr = self._ref_arrays()
+        obs, no = self._obs_arrays(d, obstacles)
+        out = d.empty(1, torch.float64)
+        nat.check(d.lib.av_planner_evaluate(d.ctx.handle, d.stream, 1, len(arr), nat.ptr(wp), nat.ptr(ref), nr,
+                                            nat.ptr(obs), no, nat.ptr(out)))
+        trajectory.cost = float(out.item())
+        return trajectory.cost
+
+    def plan(self, current_state: Tuple[float, float, float, float],
+             obstacles: Optional[List[Tuple[float, float, float]]] = None) -> Tuple[Trajectory, List[Trajectory]]:
+        self._configure()
+        d = self._dev
+        st = d.upload(np.asarray(current_state, np.float64).reshape(1, 4), np.float64)
+        ref, nr = self._ref_arrays()
+        obs, no = self._obs_arrays(d, obstacles)
+        wp = d.empty((1, self._c, self._n, nat.WP_DOUBLES), torch.float64)
+        cost = d.empty((1, self._c), torch.float64)
+        order = d.empty((1, self._c), torch.int32)
+        nat.check(d.lib.av_planner_plan(d.ctx.handle, d.stream, 1, nat.ptr(st), nat.ptr(ref), nr, nat.ptr(obs), no,
+                                        nat.ptr(wp), nat.ptr(cost), nat.ptr(order)))
+        wph, costh, orderh = wp.cpu().numpy()[0], cost.cpu().numpy()[0], order.cpu().numpy()[0]
+        gen = []
+        for c in range(self._c):
+            lat = self._lat[c // 3]
+            kind = "lane_keep" if abs(lat) < 0.5 else ("lane_change_left" if lat < 0 else "lane_change_right")
+            gen.append(Trajectory(waypoints=_to_waypoints(wph[c]), cost=float(costh[c]), trajectory_type=kind))
+        candidates = [gen[int(c)] for c in orderh]
+        return (candidates[0] if candidates else None), candidates
+
+    def draw_trajectories(self, frame: np.ndarray, optimal: Optional[Trajectory], candidates: List[Trajectory],
+                          transform_func=None, draw_all: bool = True) -> np.ndarray:
+        """Polyline rendering (display only, not on the hot path)."""
+        import cv2
+        out = frame.copy()
+        if transform_func is None:
+            h, w = frame.shape[:2]
+
+            def transform_func(x, y):
+                return int(w / 2 + x * 10), int(h - y * 10 - 50)
+        if draw_all:
+            worst = max((t.cost for t in candidates), default=0.0) + 1
+            for t in candidates:
+                if t == optimal or len(t.waypoints) < 2:
+                    continue
+                ratio = t.cost / worst
+                pts = np.array([transform_func(w.x, w.y) for w in t.waypoints]).reshape((-1, 1, 2)).astype(np.int32)
+                cv2.polylines(out, [pts], False, (0, int(255 * (1 - ratio)), int(255 * ratio)), 1)
+        if optimal and len(optimal.waypoints) >= 2:
+            pts = np.array([transform_func(w.x, w.y) for w in optimal.waypoints]).reshape((-1, 1, 2)).astype(np.int32)
+            cv2.polylines(out, [pts], False, (0, 255, 0), 4)
+            cv2.polylines(out, [pts], False, (100, 255, 100), 2)
+            for w in optimal.waypoints[::5]:
+                cv2.circle(out, transform_func(w.x, w.y), 3, (255, 255, 0), -1)
+        return out
+
+    def reset(self):
+        self.reference_trajectory = None

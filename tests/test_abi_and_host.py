@@ -1,0 +1,131 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/avhot.h declares; host-side logic."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(nat.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return nat.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = nat.declared_symbols()
+    assert len(names) >= 29
+    for n in names:
+        assert hasattr(lib, n), "libavhot.so lacks %s declared in include/avhot.h" % n
+    assert lib.av_version() == 100
+    assert {s[0] for s in nat._SIGS + nat._OPTIONAL_SIGS} >= set(names), "ctypes binding missing for a declared symbol"
+
+
+def test_struct_layouts_match_header(lib):
+    assert np.dtype(nat.TRACK_ROW_FIELDS).itemsize == nat.TRACK_ROW_BYTES == 64
+    assert C.sizeof(nat.TrackerCfg) == 24 and C.sizeof(nat.KfCfg) == 24 and C.sizeof(nat.PlannerCfg) == 56
+    assert lib.av_tracker_state_bytes(64, 50) == 64 + 64 * 64 + 64 * 50 * 32
+    assert lib.av_tracker_state_bytes(0, 50) == 0
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    n = C.c_int(-1)
+    assert lib.av_device_count(C.byref(n)) == 0 and n.value == 0
+    h = C.c_void_p()
+    rc = lib.av_ctx_create(0, C.byref(h))
+    assert rc == -3 and b"no HIP device" in lib.av_last_error_string()
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        from src.planning import MotionPlanner
+        MotionPlanner()
+    with pytest.raises(RuntimeError):
+        from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+        HotLoop()
+
+
+def test_argument_validation_without_gpu(lib):
+    assert lib.av_planner_configure(None, None) == -1
+    assert lib.av_ctx_destroy(None) == 0
+    assert lib.av_graph_launch(None, 0, None) == -1
+
+
+def test_dataclass_surfaces():
+    from src.perception import ObjectDetector
+    from src.planning import Trajectory, Waypoint
+    from src.tracking import Track
+    from multimodal_autonomous_driving_perception_and_planning_amd.perception import Detection
+    d = Detection(bbox=(0, 519, 104, 597), class_id=0, class_name="car", confidence=0.5)
+    assert d.center == (52.0, 558.0)
+    t = Track(track_id=1, bbox=(0, 0, 10, 20), class_id=0, class_name="car", confidence=0.9)
+    assert t.center == (5.0, 10.0) and t.velocity is None and t.predict_next_position() == (5.0, 10.0)
+    t.velocities.append((1.0, -2.0))
+    assert t.predict_next_position() == (6.0, 8.0)
+    a = Trajectory(waypoints=[Waypoint(0, 0, 0, 1, 0.0), Waypoint(3, 4, 0, 1, 0.5)])
+    b = Trajectory(waypoints=[Waypoint(0, 0, 0, 1, 0.0), Waypoint(3, 4, 0, 1, 0.5)])
+    assert a == b and a.length == 5.0 and a.duration == 0.5 and a.get_positions().shape == (2, 2)
+    b.cost = 1.0
+    assert a != b
+    assert Trajectory(waypoints=[]).length == 0.0 and Trajectory(waypoints=[]).duration == 0.0
+    assert ObjectDetector.CLASSES[7] == "stop_sign" and len(ObjectDetector.CLASS_COLORS) == 8
+
+
+def test_shard_streams_partition():
+    from multimodal_autonomous_driving_perception_and_planning_amd.distributed import shard_streams
+    for total, world in ((512, 8), (10, 4), (3, 8), (64, 1)):
+        spans = [shard_streams(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_streams(512, 8, 3) == (192, 256)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from multimodal_autonomous_driving_perception_and_planning_amd import distributed as D
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, tcap = 3, 64
+        rows = np.zeros((S, tcap), np.dtype(nat.TRACK_ROW_FIELDS))
+        counts = np.zeros(S, np.int32)
+        for s in range(S):
+            n = 1 + ((rank * S + s) % 5)
+            counts[s] = n
+            rows["id"][s, :n] = 1000 * (rank * S + s) + np.arange(n)
+            rows["conf"][s, :n] = 0.5 + rank
+            rows["x2"][s, :n] = 7 * s + rank
+        msg = D.pack_tables(torch.as_tensor(rows.view(np.uint8).reshape(S, tcap, 64)), torch.as_tensor(counts))
+        out = D.all_gather_tables(msg, world)
+        r2, c2 = D.unpack_tables(out, tcap)
+        ok = r2.shape == (world * S, tcap)
+        for g in range(world * S):
+            n = 1 + (g % 5)
+            ok &= int(c2[g]) == n and list(r2["id"][g, :n]) == list(1000 * g + np.arange(n))
+            ok &= float(r2["conf"][g, 0]) == 0.5 + g // S and int(r2["x2"][g, 0]) == 7 * (g % S) + g // S
+        lo, hi = D.shard_streams(world * S, world, rank)
+        ok &= (lo, hi) == (rank * S, rank * S + S)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_track_table_allgather_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,187 @@
+"""The five drop-in classes driven the way demo.py drives them, against reference goldens / CPU oracle."""
+import numpy as np
+import pytest
+
+from tests._util import orders_equivalent
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    import src.perception as P
+    import src.planning as PL
+    import src.state_estimation as SE
+    import src.tracking as T
+    return P, T, SE, PL
+
+
+def test_object_detector_simulated(api, golden):
+    P = api[0]
+    g = golden("detections")
+    det = P.ObjectDetector(mode="simulated")
+    frame = np.zeros((720, 1280, 3), np.uint8)
+    for f in range(120):
+        out = det.detect(frame)
+        assert len(out) == g["n_720"][f]
+        for j, d in enumerate(out):
+            assert d.bbox == tuple(g["box_720"][f, j]) and d.class_id == g["cls_720"][f, j]
+            assert d.confidence == g["conf_720"][f, j]
+            assert d.class_name == P.ObjectDetector.CLASSES[d.class_id]
+            assert d.center == ((d.bbox[0] + d.bbox[2]) / 2, (d.bbox[1] + d.bbox[3]) / 2)
+    assert det.frame_count == 120
+    det.reset()
+    assert det.frame_count == 0
+    again = det.detect(frame)
+    assert [d.bbox for d in again] == [tuple(b) for b in g["box_720"][0, :g["n_720"][0]]]
+    # yolo mode without a model path behaves like the reference: simulated output
+    d2 = P.ObjectDetector(mode="yolo")
+    assert [d.bbox for d in d2.detect(frame)] == [d.bbox for d in again]
+
+
+@pytest.mark.parametrize("case,kw", [("tracker_sim720", {}),
+                                     ("tracker_ties", dict(iou_threshold=0.5, max_age=2, min_hits=1, trajectory_length=5))])
+def test_multi_object_tracker_objects(api, golden, case, kw):
+    P, T = api[0], api[1]
+    g = golden(case)
+    trk = T.MultiObjectTracker(**kw)
+    seen = {}
+    nfr = min(len(g["in_n"]), 160)
+    for f in range(nfr):
+        dets = [P.Detection(bbox=tuple(int(v) for v in g["in_box"][f, j]), class_id=int(g["in_cls"][f, j]),
+                            class_name=P.ObjectDetector.CLASSES[int(g["in_cls"][f, j])],
+                            confidence=float(g["in_conf"][f, j])) for j in range(g["in_n"][f])]
+        res = trk.update(dets)
+        assert [t.track_id for t in res] == list(g["conf_ids"][f][:g["n_conf"][f]]), f
+        assert list(trk.tracks.keys()) == list(g["ids"][f][:g["n_live"][f]]), f
+        assert trk.next_id == g["next_id"][f] and trk.frame_count == f + 1
+        for r, t in enumerate(trk.tracks.values()):
+            assert t.bbox == tuple(g["box"][f, r]) and t.class_id == g["cls"][f, r]
+            assert (t.age, t.hits, t.misses) == tuple(g["ahm"][f, r]) and t.confidence == g["conf"][f, r]
+            assert seen.setdefault(t.track_id, t) is t          # object identity is stable across frames
+        key = "traj_%d" % (f + 1)
+        if key in g.files:
+            for r, t in enumerate(trk.tracks.values()):
+                tl, vl = g["traj_len_%d" % (f + 1)][r], g["vel_len_%d" % (f + 1)][r]
+                assert np.array_equal(np.array(t.trajectory).reshape(-1, 2), g[key][r, :tl])
+                assert np.array_equal(np.array(t.velocities).reshape(-1, 2), g["vel_%d" % (f + 1)][r, :vl])
+                assert (t.velocity is None) == (vl == 0)
+    assert set(trk.get_all_trajectories()) == {t.track_id for t in trk.tracks.values() if t.hits >= trk.min_hits}
+    trk.reset()
+    assert trk.tracks == {} and trk.next_id == 1 and trk.frame_count == 0
+    assert trk.update([]) == []
+
+
+def test_tracker_grows_past_initial_capacity(api):
+    P, T = api[0], api[1]
+    from oracle.tracker_ref import TrackerRef
+    trk = T.MultiObjectTracker(min_hits=1, max_age=200, capacity=64)
+    ref = TrackerRef(min_hits=1, max_age=200)
+    rng = np.random.RandomState(3)
+    for f in range(12):
+        n = 12
+        x = rng.randint(0, 1100, size=n)
+        y = rng.randint(0, 600, size=n)
+        box = np.stack([x, y, x + 40, y + 40], axis=1).astype(np.int32)
+        dets = [P.Detection(bbox=tuple(int(v) for v in b), class_id=0, class_name="car", confidence=0.9) for b in box]
+        trk.update(dets)
+        ref.update(n, box, np.zeros(n, np.int32), np.full(n, 0.9))
+        assert list(trk.tracks.keys()) == [r["id"] for r in ref.rows]
+    assert len(trk.tracks) > 64 and trk._tcap >= 128
+
+
+def test_vehicle_state_estimator(api):
+    SE = api[2]
+    from oracle.harness_ref import ego_motion
+    from oracle.kf_ref import KalmanRef, STATE_FIELDS
+    est, ref = SE.VehicleStateEstimator(), KalmanRef()
+    z = ego_motion(60)
+    for f in range(60):
+        if f % 7 == 3:
+            got, want = est.step(), ref.step(None)
+        elif f % 11 == 5:
+            est.predict(), ref.predict()
+            got, want = est.update(z[f]), ref.update(z[f])
+        else:
+            got, want = est.step(z[f]), ref.step(z[f])
+        for k, name in enumerate(STATE_FIELDS):
+            assert getattr(got, name) == pytest.approx(want[k], rel=1e-9, abs=1e-9), (f, name)
+    assert len(est.state_history) == len(ref.history) == 60
+    np.testing.assert_allclose(est.kf.x, ref.x, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(est.kf.P, ref.P, rtol=1e-10, atol=1e-12)
+    assert est.time == pytest.approx(ref.time)
+    assert est.get_trajectory().shape == (60, 2) and est.get_speed_history()[0].shape == (60,)
+    est.set_initial_state(1.0, 2.0, 3.0, 4.0)
+    ref.set_initial_state(1.0, 2.0, 3.0, 4.0)
+    assert est.prev_speed == 5.0
+    got, want = est.step(z[0]), ref.step(z[0])
+    assert got.acceleration == pytest.approx(want[6], rel=1e-9) and got.yaw_rate == pytest.approx(want[7], rel=1e-9, abs=1e-9)
+    est.reset()
+    assert est.state_history == [] and est.time == 0.0 and np.array_equal(est.kf.P, np.eye(6) * 10)
+    with pytest.raises(ValueError):
+        est.update([1.0, 2.0])
+
+
+def test_motion_planner(api, golden):
+    PL = api[3]
+    g = golden("planner")
+    p = PL.MotionPlanner()
+    for s in (0, 2, 5):
+        opt, cands = p.plan(tuple(g["states"][s]))
+        assert len(cands) == 21 and opt is cands[0] and len(opt.waypoints) == 51
+        costs = np.array([t.cost for t in cands])
+        assert np.all(np.diff(costs) >= 0)
+        np.testing.assert_allclose(np.sort(costs), np.sort(g["cost"][s]), rtol=1e-12)
+        names = {0: "lane_keep", 1: "lane_change_left", 2: "lane_change_right"}
+        gen_types = [names[t] for t in g["types"][s]]
+        assert sorted(t.trajectory_type for t in cands) == sorted(gen_types)
+        w = np.array([[q.x, q.y, q.heading, q.velocity, q.timestamp, q.curvature] for q in opt.waypoints])
+        np.testing.assert_allclose(w, g["wp_first8"][s][g["order"][s][0]], rtol=1e-12, atol=1e-11)
+        assert opt.length == pytest.approx(g["length"][s][g["order"][s][0]], rel=1e-12)
+        assert opt.duration == pytest.approx(5.0)
+        assert cands[1] != opt and opt == opt
+    # generate + evaluate reproduce plan()'s candidate and cost
+    t = p.generate_polynomial_trajectory(tuple(g["states"][2]), -3.5, 8.0)
+    w = np.array([[q.x, q.y, q.heading, q.velocity, q.timestamp, q.curvature] for q in t.waypoints])
+    np.testing.assert_allclose(w, g["wp_first8"][2][0], rtol=1e-12, atol=1e-11)
+    assert p.evaluate_trajectory_cost(t) == pytest.approx(g["cost"][2][0], rel=1e-12)
+    assert p.evaluate_trajectory_cost(PL.Trajectory(waypoints=[])) == float("inf")
+    # reference path + obstacles
+    obs = [tuple(o) for o in g["obstacles"]]
+    p.set_reference_path([tuple(r) for r in g["ref_path"]])
+    np.testing.assert_allclose([w.heading for w in p.reference_trajectory.waypoints], g["ref_heading"], rtol=1e-14)
+    for s in range(4):
+        opt, cands = p.plan(tuple(g["states"][s]), obs)
+        np.testing.assert_allclose(sorted(t.cost for t in cands), np.sort(g["cost_refobs"][s]), rtol=1e-12)
+        assert p.evaluate_trajectory_cost(cands[3], obs) == pytest.approx(cands[3].cost, rel=1e-12)
+    p.reset()
+    assert p.reference_trajectory is None
+    # non-default construction
+    q = PL.MotionPlanner(planning_horizon=3.0, dt=0.2, num_samples=5)
+    opt, cands = q.plan(tuple(g["states"][1]))
+    assert len(cands) == 15 and len(opt.waypoints) == 16
+    np.testing.assert_allclose(sorted(t.cost for t in cands), np.sort(g["alt_cost"][1]), rtol=1e-12)
+    # the first planner still works after another configuration used the shared context
+    opt, _ = p.plan(tuple(g["states"][0]))
+    assert len(opt.waypoints) == 51
+
+
+def test_demo_style_loop_matches_cpu_oracle(api):
+    P, T, SE, PL = api
+    from oracle.harness_ref import run_stream
+    N = 40
+    want = run_stream(N)
+    det, trk, est, pl = P.ObjectDetector(), T.MultiObjectTracker(), SE.VehicleStateEstimator(), PL.MotionPlanner()
+    frame = np.zeros((720, 1280, 3), np.uint8)
+    for f in range(N):
+        dets = det.detect(frame)
+        tracks = trk.update(dets)
+        st = est.step(np.array(want["z"][f]))
+        opt, cands = pl.plan((st.x, st.y, st.heading, st.speed))
+        assert [t.track_id for t in trk.tracks.values()] == list(want["ids"][f][:want["n_live"][f]])
+        assert len(tracks) == int((want["ahm"][f][:want["n_live"][f], 1] >= 3).sum())
+        assert st.speed == pytest.approx(want["state"][f][5], rel=1e-9)
+        assert opt.cost == pytest.approx(np.min(want["cost"][f]), rel=1e-9)
