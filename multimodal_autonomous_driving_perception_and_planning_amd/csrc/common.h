@@ -65,6 +65,30 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// DPP moves (no LDS round trip).  ctrl: quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast:15 0x142, row_bcast:31 0x143, wave_shr:1 0x138 (lane i <- lane i-1), wave_shl:1 0x130.
+template <int CTRL, int ROW_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, BOUND);
+    const int nhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, BOUND);
+    return __hiloint2double(nhi, nlo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Deterministic wave-wide sum (fixed tree), result uniform in every lane.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov_f64<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);          // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);          // row_mirror
+    v += dpp_mov_f64<0x142, 0xA>(v);     // row_bcast:15 -> rows 1,3
+    v += dpp_mov_f64<0x143, 0xC>(v);     // row_bcast:31 -> rows 2,3
+    return readlane_f64(v, 63);
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

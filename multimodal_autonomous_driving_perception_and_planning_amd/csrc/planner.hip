@@ -24,6 +24,8 @@
 
 #include <cmath>
 
+
+
 namespace {
 
 struct PlanParams {
@@ -40,10 +42,12 @@ __host__ __device__ inline size_t plan_lds_doubles(int G, int n, int C) {
     return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + even_up(G * C) + (size_t)4 * n * 6;
 }
 
+// Orders this wave's LDS accesses for the compiler.  The hardware executes one wave's DS operations
+// in issue order, so no s_waitcnt is needed (and none for outstanding global stores either).
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 template <int G>
@@ -188,6 +192,211 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
         for (int o2 = 0; o2 < C; ++o2) {
             const double v = cc[o2];
             rank += (v < mine || (v == mine && o2 < c)) ? 1 : 0;
+        }
+        cost[(size_t)f * C + c] = mine;
+        order[(size_t)f * C + rank] = c;
+    }
+}
+
+// Throughput variant for large batches and n <= 64: every wave is autonomous (no workgroup barrier).
+// A wave owns FPW consecutive start states; lane = waypoint index, so the per-waypoint constants
+// (1-exp(-t_i), quintic blend, timestamp) sit in registers for the whole kernel.
+//   1a  all lanes: velocity profile + acceleration cost terms of the 3*FPW (state, speed) pairs
+//   1b  3*FPW lanes: the reference's sequential sums (prefix s_i, velocity cost, acceleration cost)
+//   2   for each of the FPW*C trajectories: positions, heading, curvature, cost, AoS tile -> HBM
+//   3   stable rank of each state's C costs
+template <int FPW, bool EXTRA>     // EXTRA: a reference path and/or obstacles take part in the cost
+__global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_states,
+                                                           const double* __restrict__ state,
+                                                           const double* __restrict__ ref, int n_ref,
+                                                           const double* __restrict__ obs, int n_obs,
+                                                           double* __restrict__ wp, double* __restrict__ cost,
+                                                           int32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = p.n, C = p.C;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t per_wave = (size_t)FPW * 3 * n * 2 + (size_t)n * 6 + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
+    double* vs = sm + wid * per_wave;                  // [FPW*3][n][2]  (v, s)
+    double* stage = vs + (size_t)FPW * 3 * n * 2;      // [n][6] AoS tile; phase 1: acc terms [FPW*3][n]
+    double* costs = stage + (size_t)n * 6;             // [FPW][C]
+    double* base = costs + even_up(FPW * C);           // [FPW*3][4]  S_v, S_a, running
+    double* trig = base + FPW * 3 * 4;                 // [FPW][8]
+    const long long gw = (long long)blockIdx.x * 4 + wid;
+    const long long f0l = gw * FPW;
+    if (f0l >= n_states) return;
+    const int f0 = (int)f0l;
+    const int nf = (n_states - f0) < FPW ? (n_states - f0) : FPW;    // states this wave really has
+
+    // All global reads of this wave happen here, in one batch: per-lane table entries (lane = waypoint
+    // index), the lateral offsets (lane = sample index) and the wave's start states.  Nothing below
+    // reads memory again, so the loops never queue behind the store traffic.
+    const bool in = lane < n;
+    const int li_c = in ? lane : n - 1;                 // clamped waypoint index of this lane
+    const int ln_c = (lane + 1 < n) ? lane + 1 : n - 1; // clamped index of the next waypoint
+    const int lp_c = li_c > 0 ? li_c - 1 : 0;
+    const double q_i = p.q[li_c], q_n = p.q[ln_c], t_i = p.t[li_c];
+    const double al_i = p.alpha[li_c], al_p = p.alpha[lp_c], dtd_i = p.dtd[li_c];
+    const double lat_l = p.lat[lane < p.n_lat ? lane : 0];
+    double st_x[FPW], st_y[FPW], st_h[FPW], st_v[FPW];
+#pragma unroll
+    for (int g = 0; g < FPW; ++g) {
+        const double4 sv4 = reinterpret_cast<const double4*>(state)[f0 + (g < nf ? g : 0)];
+        st_x[g] = sv4.x, st_y[g] = sv4.y, st_h[g] = sv4.z, st_v[g] = sv4.w;
+    }
+
+    // ---- 1a: lane = waypoint; velocity profile and acceleration cost term of every (state, speed) -----
+#pragma unroll
+    for (int g = 0; g < FPW; ++g) {
+        if (g < nf) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int pair = g * 3 + k;
+                const double v0 = st_v[g];
+                const double dv = (8.0 + 2.0 * (double)k) - v0;
+                const double v = v0 + dv * al_i;                       // :153-154
+                const double vp = v0 + dv * al_p;
+                const double a = (v - vp) / dtd_i;
+                const double acc = (lane > 0 && dtd_i > 0.0) ? p.w_acc * (a * a) : 0.0;   // :240-244
+                if (in) {
+                    vs[((size_t)pair * n + lane) * 2] = v;
+                    stage[(size_t)pair * n + lane] = acc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < FPW; ++g) {
+        if (g < nf && lane == 32 + g) {
+            const double h0 = st_h[g];
+            const double hp = h0 + 1.5707963267948966;
+            double* tg = trig + g * 8;
+            tg[0] = st_x[g], tg[1] = st_y[g];
+            tg[2] = cos(h0), tg[3] = sin(h0), tg[4] = cos(hp), tg[5] = sin(hp), tg[6] = h0;
+        }
+    }
+    wave_lds_fence();
+    // ---- 1b: 3*nf lanes run the reference's sequential sums over LDS-resident terms -----------------
+    if (lane < nf * 3) {
+        double* o = vs + (size_t)lane * n * 2;
+        const double* ac = stage + (size_t)lane * n;
+        double s = 0.0, sv = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double v = o[2 * i];
+            if (i > 0) s = s + v * p.dt;                               // :157
+            o[2 * i + 1] = s;
+            const double e = v - 10.0;
+            sv = sv + p.w_vel * (e * e);                               // :236
+        }
+        double run = sv, sa = 0.0;
+        for (int i = 1; i < n; ++i) {                                  // zero terms stand for skipped ones
+            const double term = ac[i];
+            run = run + term, sa = sa + term;
+        }
+        double* b = base + lane * 4;
+        b[0] = sv, b[1] = sa, b[2] = run;
+    }
+    wave_lds_fence();
+
+    // ---- 2 -----------------------------------------------------------------------------------------
+    // Lanes >= n run the same arithmetic on a clamped index (no predication inside the loop); their
+    // results are dropped at the sum and at the store.
+    // software pipeline over trajectories: tile(c) is staged in LDS at the end of iteration c and
+    // written to HBM during iteration c+1 (n*3 16-byte chunks: lanes, lanes+64, and a tail of `tail`).
+    const int n3 = n * 3;                                   // 16-byte chunks per trajectory (153 for n = 51)
+    const bool c0 = lane < n3, c1 = lane + 64 < n3, c2 = lane + 128 < n3;
+    const int q0 = c0 ? lane : 0, q1 = c1 ? lane + 64 : 0, q2 = c2 ? lane + 128 : 0;
+    bool pending = false;
+    double2* pdst = nullptr;
+    double2 r0 = make_double2(0.0, 0.0), r1 = r0, r2 = r0;
+    for (int g = 0; g < nf; ++g) {
+        const int f = f0 + g;
+        const double* tg = trig + g * 8;
+        const double x0 = tg[0], y0 = tg[1], cs = tg[2], sn = tg[3], c2 = tg[4], s2 = tg[5], h0 = tg[6];
+        for (int k = 0; k < 3; ++k) {
+            const double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
+            const double v = o[2 * li_c], s = o[2 * li_c + 1], s1 = o[2 * ln_c + 1];
+            const double bx = x0 + s * cs, by = y0 + s * sn;         // :175-176
+            const double bx1 = x0 + s1 * cs, by1 = y0 + s1 * sn;
+            const double den = v * p.dt + 1e-6;                      // :196 denominator
+            const double* b = base + (g * 3 + k) * 4;
+            const double b0 = b[0], b1 = b[1], b2 = b[2];
+            for (int li = 0; li < p.n_lat; ++li) {
+                const int c = li * 3 + k;
+                if (pending) {           // issue the LDS reads of the staged tile early; consumed after the math
+                    wave_lds_fence();
+                    const double2* src = reinterpret_cast<const double2*>(stage);
+                    r0 = src[q0], r1 = src[q1], r2 = src[q2];
+                    wave_lds_fence();
+                }
+                const double df = readlane_f64(lat_l, li);
+                const double d = df * q_i, d1 = df * q_n;
+                const double x = bx + d * c2, y = by + d * s2;       // :179-180
+                const double x1 = bx1 + d1 * c2, y1 = by1 + d1 * s2;
+                double hd = atan2(y1 - y, x1 - x);                   // :188
+                const double hprev = dpp_mov_f64<0x138>(hd);         // lane i <- lane i-1
+                double curv = (hd - hprev) / den;
+                curv = (lane > 0 && lane < n - 1) ? curv : 0.0;
+                if (lane == n - 1) hd = n > 1 ? hprev : h0;          // :190
+                double lat_sum = 0.0, obs_sum = 0.0;
+                if (EXTRA && n_ref > 0) {
+                    double md = INFINITY;
+                    for (int r = 0; r < n_ref; ++r) {
+                        const double dx = ref[2 * r] - x, dy = ref[2 * r + 1] - y;
+                        const double dd = sqrt(dx * dx + dy * dy);
+                        md = dd < md ? dd : md;
+                    }
+                    lat_sum = wave_sum_dpp(in ? p.w_lat * (md * md) : 0.0);
+                }
+                if (EXTRA && n_obs > 0) {
+                    for (int q = 0; q < n_obs; ++q) {
+                        const double ox = obs[3 * q], oy = obs[3 * q + 1], rad = obs[3 * q + 2];
+                        const double ex = x - ox, ey = y - oy;
+                        const double dist = sqrt(ex * ex + ey * ey);
+                        if (dist < rad * 2.0) obs_sum += 1000.0 * (rad * 2.0 - dist);
+                        else if (dist < rad * 4.0) obs_sum += 10.0 / (dist - rad + 0.1);
+                    }
+                    obs_sum = wave_sum_dpp(in ? obs_sum : 0.0);
+                }
+                const double curv_sum = wave_sum_dpp(in ? p.w_curv * (curv * curv) : 0.0);
+                if (lane == 0) {
+                    const double va = (EXTRA && n_ref > 0) ? (lat_sum + b0) + b1 : b2;
+                    costs[g * C + c] = EXTRA ? (va + curv_sum) + obs_sum : va + curv_sum;
+                }
+                if (wp) {
+                    // The tile of the previous trajectory was read into r0..r2 at the top of this
+                    // iteration; stream it out now (contiguous 16 B per lane), then stage this one.
+                    if (pending) {
+                        if (c0) pdst[q0] = r0;
+                        if (c1) pdst[q1] = r1;
+                        if (c2) pdst[q2] = r2;
+                    }
+                    if (in) {
+                        double2* w = reinterpret_cast<double2*>(stage + (size_t)lane * 6);
+                        w[0] = make_double2(x, y), w[1] = make_double2(hd, v), w[2] = make_double2(t_i, curv);
+                    }
+                    pdst = reinterpret_cast<double2*>(wp + ((size_t)f * C + c) * n * 6);
+                    pending = true;
+                }
+            }
+        }
+    }
+    if (pending) {
+        wave_lds_fence();
+        const double2* src = reinterpret_cast<const double2*>(stage);
+        if (c0) pdst[q0] = src[q0];
+        if (c1) pdst[q1] = src[q1];
+        if (c2) pdst[q2] = src[q2];
+    }
+    wave_lds_fence();
+    // ---- 3 -----------------------------------------------------------------------------------------
+    for (int idx = lane; idx < nf * C; idx += 64) {
+        const int g = idx / C, c = idx - g * C, f = f0 + g;
+        const double* cc = costs + g * C;
+        const double mine = cc[c];
+        int rank = 0;
+        for (int o2 = 0; o2 < C; ++o2) {
+            const double vv = cc[o2];
+            rank += (vv < mine || (vv == mine && o2 < c)) ? 1 : 0;
         }
         cost[(size_t)f * C + c] = mine;
         order[(size_t)f * C + rank] = c;
@@ -398,12 +607,28 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
     const int n = ctx->n_points, C = ctx->n_cand;
     PlanParams p;
     fill_params(ctx, p);
+    hipStream_t st = as_stream(stream);
+    if (n <= 64 && n_states >= 1024) {
+        constexpr int FPW = 2;
+        const size_t per_wave = (size_t)FPW * 3 * n * 2 + (size_t)n * 6 + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
+        const size_t lds_w = per_wave * 4 * sizeof(double);
+        if (lds_w <= 64 * 1024) {
+            const int grid_w = (n_states + 4 * FPW - 1) / (4 * FPW);
+            if (n_ref > 0 || n_obs > 0)
+                hipLaunchKernelGGL((planner_wave_kernel<FPW, true>), dim3(grid_w), dim3(256), lds_w, st, p, n_states, state,
+                                   ref_path, n_ref, obstacles, n_obs, waypoints, cost, order);
+            else
+                hipLaunchKernelGGL((planner_wave_kernel<FPW, false>), dim3(grid_w), dim3(256), lds_w, st, p, n_states, state,
+                                   ref_path, n_ref, obstacles, n_obs, waypoints, cost, order);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
+    }
     int G = n_states >= 4096 ? 8 : (n_states >= 1024 ? 4 : (n_states >= 512 ? 2 : 1));
     while (G > 1 && plan_lds_doubles(G, n, C) * 8 > 48 * 1024) G >>= 1;
     const size_t lds = plan_lds_doubles(G, n, C) * 8;
     AV_REQUIRE(lds <= 64 * 1024, AV_EINVAL, "av_planner_plan: configuration needs %zu B of LDS", lds);
     const int grid = (n_states + G - 1) / G;
-    hipStream_t st = as_stream(stream);
 #define AV_PLAN_LAUNCH(GG)                                                                                        \
     hipLaunchKernelGGL(planner_kernel<GG>, dim3(grid), dim3(256), lds, st, p, n_states, state, ref_path, n_ref,  \
                        obstacles, n_obs, waypoints, cost, order)
