@@ -89,13 +89,24 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return readlane_f64(v, 63);
 }
 
+// DPP move whose unwritten lanes (row_mask) keep their own value -- neutral for max/min.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_mov_keep_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(nhi, nlo);
+}
+__device__ __forceinline__ double fmax_nn(double a, double b) { return b > a ? b : a; }
+// Wave-wide maximum (no NaNs expected), result uniform in every lane.
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = fmax_nn(v, dpp_mov_keep_f64<0xB1>(v));
+    v = fmax_nn(v, dpp_mov_keep_f64<0x4E>(v));
+    v = fmax_nn(v, dpp_mov_keep_f64<0x141>(v));
+    v = fmax_nn(v, dpp_mov_keep_f64<0x140>(v));
+    v = fmax_nn(v, dpp_mov_keep_f64<0x142, 0xA>(v));
+    v = fmax_nn(v, dpp_mov_keep_f64<0x143, 0xC>(v));
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll

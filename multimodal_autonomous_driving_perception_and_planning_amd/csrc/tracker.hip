@@ -39,15 +39,27 @@ __device__ __forceinline__ double iou_f64(int ax1, int ay1, int ax2, int ay2, in
     return uni > 0 ? (double)inter / (double)uni : 0.0;
 }
 
+// Same value through float64: every factor is an int32 converted exactly, every product/sum stays an
+// exact integer below 2^53 for coordinates |x| < 2^25, so inter/uni is the identical correctly rounded
+// quotient -- at a fraction of the int64 instruction count.
+__device__ __forceinline__ double iou_fast(int ax1, int ay1, int ax2, int ay2, double a1, int bx1, int by1, int bx2,
+                                           int by2) {
+    const int xi1 = ax1 > bx1 ? ax1 : bx1, yi1 = ay1 > by1 ? ay1 : by1;
+    const int xi2 = ax2 < bx2 ? ax2 : bx2, yi2 = ay2 < by2 ? ay2 : by2;
+    const int iw = xi2 - xi1, ih = yi2 - yi1;
+    if (iw <= 0 || ih <= 0) return 0.0;
+    const double inter = (double)iw * (double)ih;
+    const double a2 = (double)(bx2 - bx1) * (double)(by2 - by1);
+    const double uni = a1 + a2 - inter;
+    return uni > 0.0 ? inter / uni : 0.0;
+}
+
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     for (int i = 0; i < n; ++i) m &= m - 1;
     return __ffsll((long long)m) - 1;
 }
 
 struct Shared {
-    int dbox[64][4];
-    int dcls[64];
-    double dconf[64];
     int d2t[64];
     double w_iou[16];
     int w_row[16];
@@ -58,15 +70,41 @@ struct Shared {
     int misc[4];
 };
 
+// Workgroup synchronisation that orders LDS traffic only.  __syncthreads() would also drain every
+// outstanding global store (s_waitcnt vmcnt(0)) -- a full HBM round trip per frame for nothing, since
+// the per-frame outputs are write-only.  A single-wave workgroup needs no barrier at all: one wave's
+// DS operations execute in issue order.
 template <bool MULTIWAVE>
+__device__ __forceinline__ void lds_sync() {
+    if (MULTIWAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
+}
+
+// DREG > 0: the row's IoU against every detection (dcap <= DREG) is computed once per frame and kept in
+// registers; DREG == 0: generic path for larger dcap (best candidate recomputed when its column is taken).
+template <bool MULTIWAVE, int DREG>
 __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
                                const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
-                               int32_t* __restrict__ det2trk) {
+                               int32_t* __restrict__ det2trk, int chunk_frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Shared& sh = *reinterpret_cast<Shared*>(smem);
     av_track_row* stage = reinterpret_cast<av_track_row*>(smem + ((sizeof(Shared) + 63) & ~size_t(63)));
+    // detections of a chunk of FC frames: n[FC] | box[FC][dcap][4] | cls[FC][dcap] | conf[FC][dcap]
+    unsigned char* chunk = reinterpret_cast<unsigned char*>(stage + tcap);
+    const int FC = chunk_frames;
+    int* c_n = reinterpret_cast<int*>(chunk);
+    int* c_box = c_n + ((FC + 3) & ~3);
+    int* c_cls = c_box + (size_t)FC * dcap * 4;
+    double* c_conf = reinterpret_cast<double*>(c_cls + (((size_t)FC * dcap + 1) & ~size_t(1)));
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -87,26 +125,40 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
         r.conf = g.conf;
     }
+    // Retire the table loads here.  Otherwise the compiler places their wait at the first use inside
+    // the frame loop, where (vmcnt counts loads and stores in order) it would also drain the previous
+    // frame's output stores on every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt/lgkmcnt untouched
     if (tid < 32) sh.slot_bits[tid] = 0;
-    __syncthreads();
+    lds_sync<MULTIWAVE>();
     if (tid < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
-    __syncthreads();
+    lds_sync<MULTIWAVE>();
 
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
-        int nd = det_n[sf];
-        nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
-        frame_count += 1;
-        if (tid < dcap) {
-            sh.d2t[tid] = -1;
-            if (tid < nd) {
-                const int4 b = reinterpret_cast<const int4*>(det_box)[sf * dcap + tid];
-                sh.dbox[tid][0] = b.x, sh.dbox[tid][1] = b.y, sh.dbox[tid][2] = b.z, sh.dbox[tid][3] = b.w;
-                sh.dcls[tid] = det_cls[sf * dcap + tid];
-                sh.dconf[tid] = det_conf[sf * dcap + tid];
+        const int fl = f % FC;
+        if (fl == 0) {
+            // one cooperative load of the next FC frames' detections; the only global reads of the loop
+            const int nfr = (n_frames - f) < FC ? (n_frames - f) : FC;
+            lds_sync<MULTIWAVE>();
+            for (int i = tid; i < nfr; i += blockDim.x) c_n[i] = det_n[sf + i];
+            const int4* gb = reinterpret_cast<const int4*>(det_box) + sf * dcap;
+            for (int i = tid; i < nfr * dcap; i += blockDim.x) reinterpret_cast<int4*>(c_box)[i] = gb[i];
+            for (int i = tid; i < nfr * dcap; i += blockDim.x) {
+                c_cls[i] = det_cls[sf * dcap + i];
+                c_conf[i] = det_conf[sf * dcap + i];
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            lds_sync<MULTIWAVE>();
         }
-        __syncthreads();
+        int nd = c_n[fl];
+        nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
+        const int* dbox = c_box + (size_t)fl * dcap * 4;        // [dcap][4]
+        const int* dcls = c_cls + (size_t)fl * dcap;
+        const double* dconf = c_conf + (size_t)fl * dcap;
+        frame_count += 1;
+        if (tid < dcap) sh.d2t[tid] = -1;
+        lds_sync<MULTIWAVE>();
 
         // ---- association (multi_object_tracker.py:113-164) ------------------------------------
         unsigned long long used = 0;          // columns already taken; identical in every thread
@@ -114,12 +166,32 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         const bool active = tid < T;
         double best = -1.0;
         int best_j = -1;
+        double ious[DREG > 0 ? DREG : 1];
+        if (DREG > 0) {
+            const double a1 = (double)(r.x2 - r.x1) * (double)(r.y2 - r.y1);
+#pragma unroll
+            for (int j = 0; j < (DREG > 0 ? DREG : 1); ++j) {
+                double v = -1.0;
+                if (active && j < nd)
+                    v = iou_fast(r.x1, r.y1, r.x2, r.y2, a1, dbox[j * 4 + 0], dbox[j * 4 + 1], dbox[j * 4 + 2], dbox[j * 4 + 3]);
+                ious[j] = (v >= cfg.iou_threshold) ? v : -1.0;          // :147  pairs below thr can never be picked
+            }
+        }
         auto recompute = [&]() {
             best = -1.0;
             best_j = -1;
+            if (DREG > 0) {
+#pragma unroll
+                for (int j = 0; j < (DREG > 0 ? DREG : 1); ++j) {
+                    const double v = ((used >> j) & 1ull) ? -1.0 : ious[j];
+                    if (v > best) best = v, best_j = j;
+                }
+                if (best < 0.0) best_j = -1;
+                return;
+            }
             for (int j = 0; j < nd; ++j) {
                 if ((used >> j) & 1ull) continue;
-                const double v = iou_f64(r.x1, r.y1, r.x2, r.y2, sh.dbox[j][0], sh.dbox[j][1], sh.dbox[j][2], sh.dbox[j][3]);
+                const double v = iou_f64(r.x1, r.y1, r.x2, r.y2, dbox[j * 4 + 0], dbox[j * 4 + 1], dbox[j * 4 + 2], dbox[j * 4 + 3]);
                 if (v > best) best = v, best_j = j;
             }
             if (!(best >= cfg.iou_threshold)) best = -1.0, best_j = -1;   // :147  max < thr -> stop
@@ -141,11 +213,11 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 }
                 if (MULTIWAVE) {
                     if (lane == 0) sh.w_iou[wid] = win_iou, sh.w_row[wid] = win_row, sh.w_col[wid] = win_col;
-                    __syncthreads();
+                    lds_sync<MULTIWAVE>();
                     win_iou = -1.0, win_row = -1, win_col = -1;
                     for (int w = 0; w < nwaves; ++w)          // ascending wave == ascending row
                         if (sh.w_iou[w] > win_iou) win_iou = sh.w_iou[w], win_row = sh.w_row[w], win_col = sh.w_col[w];
-                    __syncthreads();
+                    lds_sync<MULTIWAVE>();
                 }
                 if (win_row < 0) break;
                 used |= 1ull << win_col;
@@ -157,12 +229,12 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         // ---- matched / missed (:182-211) ---------------------------------------------------------
         if (active) {
             if (matched_j >= 0) {
-                const int nx1 = sh.dbox[matched_j][0], ny1 = sh.dbox[matched_j][1];
-                const int nx2 = sh.dbox[matched_j][2], ny2 = sh.dbox[matched_j][3];
+                const int nx1 = dbox[matched_j * 4 + 0], ny1 = dbox[matched_j * 4 + 1];
+                const int nx2 = dbox[matched_j * 4 + 2], ny2 = dbox[matched_j * 4 + 3];
                 const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
                 const double ncx = (double)(nx1 + nx2) / 2.0, ncy = (double)(ny1 + ny2) / 2.0;
                 r.x1 = nx1, r.y1 = ny1, r.x2 = nx2, r.y2 = ny2;
-                r.conf = sh.dconf[matched_j];
+                r.conf = dconf[matched_j];
                 r.age += 1, r.hits += 1, r.misses = 0;
                 double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + (r.hlen % L)) * 4);
                 *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
@@ -192,14 +264,14 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 const int b = __popcll(unm & ((1ull << tid) - 1ull));
                 sh.d2t[tid] = next_id + b;
             }
-            __syncthreads();
+            lds_sync<MULTIWAVE>();
             if (tid >= T && tid < T + nb_fit) {
                 const int b = tid - T;
                 const int j = nth_set_bit(unm, b);
                 r.id = next_id + b;
-                r.x1 = sh.dbox[j][0], r.y1 = sh.dbox[j][1], r.x2 = sh.dbox[j][2], r.y2 = sh.dbox[j][3];
-                r.cls = sh.dcls[j];
-                r.conf = sh.dconf[j];
+                r.x1 = dbox[j * 4 + 0], r.y1 = dbox[j * 4 + 1], r.x2 = dbox[j * 4 + 2], r.y2 = dbox[j * 4 + 3];
+                r.cls = dcls[j];
+                r.conf = dconf[j];
                 r.age = 0, r.hits = 1, r.misses = 0;
                 r.slot = sh.birth_slot[b];
                 r.hlen = 1;
@@ -214,7 +286,16 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         // ---- deaths (:228-233): order-preserving compaction --------------------------------------
         const bool live_row = tid < T;
         const bool dead = live_row && (r.misses > cfg.max_age);
-        const int any_dead = __syncthreads_or(dead ? 1 : 0);
+        int any_dead;
+        if (MULTIWAVE) {
+            if (tid == 0) sh.misc[0] = 0;
+            lds_sync<MULTIWAVE>();
+            if (dead) sh.misc[0] = 1;
+            lds_sync<MULTIWAVE>();
+            any_dead = sh.misc[0];
+        } else {
+            any_dead = __ballot(dead) != 0ull;
+        }
         if (any_dead) {
             const bool keep = live_row && !dead;
             const unsigned long long kb = __ballot(keep);
@@ -222,7 +303,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
             int total = __popcll(kb);
             if (MULTIWAVE) {
                 if (lane == 0) sh.w_cnt[wid] = total;
-                __syncthreads();
+                lds_sync<MULTIWAVE>();
                 total = 0;
                 for (int w = 0; w < nwaves; ++w) {
                     if (w < wid) pos += sh.w_cnt[w];
@@ -237,7 +318,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 g.flags = 0, g.conf = r.conf, g.reserved = 0.0;
                 stage[pos] = g;
             }
-            __syncthreads();
+            lds_sync<MULTIWAVE>();
             T = total;
             if (tid < T) {
                 const av_track_row g = stage[tid];
@@ -260,7 +341,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
             if (tid == 0) snap_n[sf] = T;
         }
         if (det2trk && tid < dcap) det2trk[sf * dcap + tid] = sh.d2t[tid];
-        __syncthreads();          // sh.d* are rewritten by the next frame
+        lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
     }
 
     // ---- persist ----------------------------------------------------------------------------------
@@ -315,13 +396,26 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
     AV_REQUIRE(cfg->iou_threshold >= 0.0, AV_EINVAL,
                "av_tracker_update: iou_threshold < 0 never terminates in the reference either");
     AV_REQUIRE((snap == nullptr) == (snap_n == nullptr), AV_EINVAL, "av_tracker_update: snap and snap_n go together");
-    const size_t lds = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
-    if (tcap == 64)
-        hipLaunchKernelGGL(tracker_kernel<false>, dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,
-                           dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk);
-    else
-        hipLaunchKernelGGL(tracker_kernel<true>, dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,
-                           dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk);
+    // chunk of frames whose detections are staged in LDS at once (~16 KB)
+    const size_t per_frame = 4 + (size_t)dcap * (16 + 4 + 8);
+    int fc = (int)(16384 / per_frame);
+    fc = fc < 1 ? 1 : (fc > 64 ? 64 : fc);
+    if (fc > n_frames) fc = n_frames;
+    const size_t chunk_bytes = (size_t)((fc + 3) & ~3) * 4 + (size_t)fc * dcap * 16 + (((size_t)fc * dcap + 1) & ~size_t(1)) * 4 +
+                               (size_t)fc * dcap * 8 + 16;
+    const size_t lds = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row) + chunk_bytes;
+#define AV_TRK_LAUNCH(MW, DR)                                                                                     \
+    hipLaunchKernelGGL((tracker_kernel<MW, DR>), dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,  \
+                       dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk, fc)
+    if (tcap == 64) {
+        if (dcap <= 8) AV_TRK_LAUNCH(false, 8);
+        else if (dcap <= 16) AV_TRK_LAUNCH(false, 16);
+        else AV_TRK_LAUNCH(false, 0);
+    } else {
+        if (dcap <= 8) AV_TRK_LAUNCH(true, 8);
+        else AV_TRK_LAUNCH(true, 0);
+    }
+#undef AV_TRK_LAUNCH
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
