@@ -197,6 +197,43 @@ int av_planner_evaluate(av_ctx* ctx, av_stream_t stream, int n_traj, int n_wp, c
                         const double* ref_path, int n_ref, const double* obstacles, int n_obs,
                         double* cost);
 
+/* ---- L1-L7: lane detector ----------------------------------------------------------------------
+ * Replaces LaneDetector.detect and its private stages (src/perception/lane_detector.py:47-218):
+ * cvtColor(BGR2GRAY) + GaussianBlur 5x5 (:66-74), median-adaptive Canny (:76-84), trapezoid ROI
+ * (:47-64,86-90), HoughLinesP(1, pi/180, 50, minLineLength=50, maxLineGap=150) (:92-103), slope split
+ * (:105-134), polyfit + EMA + 50-point resampling (:136-176). */
+typedef struct {
+    int32_t hough_threshold;     /* 50  (:98)  */
+    int32_t min_line_length;     /* 50  (:99)  */
+    int32_t max_line_gap;        /* 150 (:100) */
+    int32_t max_segments;        /* capacity of the per-frame segment list */
+    double smoothing_factor;     /* 0.7 (:45)  */
+} av_lane_cfg;
+
+/* Scratch the caller allocates once (blurred image, NMS map, union-find labels, edge maps, point list,
+ * Hough accumulator, segments).  av_lane_workspace_init zero-fills it (required before first use). */
+size_t av_lane_workspace_bytes(int n_streams, int h, int w, int max_segments);
+int av_lane_workspace_init(av_ctx* ctx, av_stream_t stream, int n_streams, int h, int w, int max_segments,
+                           void* workspace);
+/* Byte range of an intermediate inside the workspace (tests, visualisation):
+ * 0 blurred u8[S][h][w], 1 NMS map, 2 Canny edges (only written when stages&1), 3 ROI-masked edges
+ * (consumed by the Hough stage: lines it finds are erased), 4 thresholds double[S][4] (lo, hi, median),
+ * 5 segments int32[S][max_segments][4], 6 segment counts int32[S], 7 Hough accumulator. */
+int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segments, size_t* offset,
+                           size_t* bytes);
+/*   bgr        u8 [S][h][w][3]
+ *   roi_rows   int32 [h][2] inclusive column range kept per row, or NULL for the default trapezoid
+ *   lane_state double [S][8]   previous smoothed fit per side: c2 c1 c0 has_prev (prev_left_fit/prev_right_fit)
+ *   poly       double [S][2][3]   x = c2*y^2 + c1*y + c0   (side 0 = left, 1 = right)
+ *   pts        int32 [S][2][50][2]
+ *   info       int32 [S][8]    valid_left valid_right n_left_segments n_right_segments n_segments n_points lo hi
+ *   conf       double [S][2]   min(1, n_side_segments / 10)
+ *   stages     bit0: also write the pre-ROI Canny edge map (view 2); bit1: stop after the pixel stages
+ *              (no Hough, no fit) */
+int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int n_streams, int h, int w,
+                   const uint8_t* bgr, const int32_t* roi_rows, void* workspace, double* lane_state,
+                   double* poly, int32_t* pts, int32_t* info, double* conf, int stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,12 @@ _SIGS = [
     ("av_planner_plan", C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
     ("av_planner_generate", C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
     ("av_planner_evaluate", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
+    ("av_lane_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("av_lane_workspace_init", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    ("av_lane_workspace_view", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_size_t)]),
+    ("av_lane_detect", C.c_int, [vp, vp, C.POINTER(LaneCfg), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                 vp, C.c_int]),
 ]
 
 # entry points added by later translation units; bound when present in the header list below

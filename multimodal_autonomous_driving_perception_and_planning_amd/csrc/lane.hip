@@ -1,0 +1,714 @@
+// L1-L7: lane detector pixel path.
+//
+// Reference: LaneDetector.detect (src/perception/lane_detector.py:178-218) and the OpenCV calls it
+// makes (:63,69,72,79,83,89,94-101); semantics restated in oracle/c/lane_ref.c.
+//
+// Pipeline per frame (S frames per launch, u8 throughout, all integer arithmetic):
+//   gray_blur_hist   BGR -> gray -> 5x5 binomial blur (LDS tiles, reflect-101), 256-bin histogram
+//   thresholds       median of the blurred image from the histogram -> Canny lo/hi          (:79-81)
+//   sobel_nms        3x3 Sobel, |gx|+|gy|, sector non-maximum suppression -> map {0 weak,1 none,2 strong}
+//                    and union-find seeds for the candidates
+//   ccl_merge        8-connected union-find over candidates; strong pixels carry the smaller labels, so a
+//                    component's root is strong iff the component holds a strong pixel (exact hysteresis,
+//                    independent of scheduling, no iteration-until-stable)
+//   finalize         edge = candidate with a strong root; AND with the trapezoid ROI; per-row counts
+//   compact          row-major list of ROI edge points (the order cv::HoughLinesP collects them in)
+//   houghp           progressive probabilistic Hough, one workgroup per frame: lane = theta
+//   fit              slope split, np.polyfit-equivalent quadratic, EMA with the previous fit, 50 points
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int TW = 128, TH = 32;            // output tile of the pixel kernels
+constexpr int NUMANGLE = 180;
+
+struct LaneWs {                              // offsets (bytes) into the caller's workspace, per launch
+    size_t blur, map, labels, edges, masked, hist, thr, rowcnt, nz, npts, accum, segs, nseg, total;
+    int numrho;
+};
+
+__host__ inline size_t al256(size_t v) { return (v + 255) & ~size_t(255); }
+
+__host__ LaneWs lane_layout(int S, int h, int w, int max_segments) {
+    LaneWs L{};
+    const size_t px = (size_t)S * h * w;
+    L.numrho = (w + h) * 2 + 1;
+    size_t o = 0;
+    L.blur = o, o = al256(o + px);
+    L.map = o, o = al256(o + px);
+    L.labels = o, o = al256(o + px * 4);
+    L.edges = o, o = al256(o + px);
+    L.masked = o, o = al256(o + px);
+    L.hist = o, o = al256(o + (size_t)S * 256 * 4);
+    L.thr = o, o = al256(o + (size_t)S * 4 * 8);             // lo, hi (as doubles) , median, spare
+    L.rowcnt = o, o = al256(o + (size_t)S * h * 4);
+    L.nz = o, o = al256(o + px * 4);                          // packed x | y << 16
+    L.npts = o, o = al256(o + (size_t)S * 4);
+    L.accum = o, o = al256(o + (size_t)S * NUMANGLE * L.numrho * 4);
+    L.segs = o, o = al256(o + (size_t)S * max_segments * 4 * 4);
+    L.nseg = o, o = al256(o + (size_t)S * 4);
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+__device__ __forceinline__ int clampi(int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); }
+
+// ---- L1: gray + blur + histogram -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gray_blur_hist_kernel(const uint8_t* __restrict__ bgr, int h, int w,
+                                                             uint8_t* __restrict__ blur, unsigned* __restrict__ hist) {
+    __shared__ uint8_t g[TH + 4][TW + 4 + 4];           // gray with halo 2
+    __shared__ unsigned short t[TH + 4][TW];            // horizontal pass
+    __shared__ unsigned lh[256];
+    const int s = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const uint8_t* img = bgr + (size_t)s * h * w * 3;
+    lh[tid] = 0;
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int r = i / (TW + 4), c = i - r * (TW + 4);
+        const int yy = reflect101(y0 + r - 2, h), xx = reflect101(x0 + c - 2, w);
+        const uint8_t* p = img + ((size_t)yy * w + xx) * 3;
+        g[r][c] = (uint8_t)((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14);
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 4) * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        t[r][c] = (unsigned short)(g[r][c] + 4 * g[r][c + 1] + 6 * g[r][c + 2] + 4 * g[r][c + 3] + g[r][c + 4]);
+    }
+    __syncthreads();
+    // each thread: 16 consecutive output pixels of one row -> one 16-byte store
+    const int r = tid >> 3, c0 = (tid & 7) * 16;
+    const int y = y0 + r;
+    if (y < h) {
+        uint8_t o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = c0 + k;
+            const int v = (t[r][c] + 4 * t[r + 1][c] + 6 * t[r + 2][c] + 4 * t[r + 3][c] + t[r + 4][c] + 128) >> 8;
+            o[k] = (uint8_t)v;
+            if (x0 + c < w) atomicAdd(&lh[v], 1u);
+        }
+        uint8_t* dst = blur + ((size_t)s * h + y) * w + x0 + c0;
+        if (x0 + c0 + 16 <= w && (((size_t)dst) & 15) == 0) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+        } else {
+            for (int k = 0; k < 16; ++k)
+                if (x0 + c0 + k < w) dst[k] = o[k];
+        }
+    }
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&hist[(size_t)s * 256 + tid], lh[tid]);
+}
+
+// ---- L2a: median -> thresholds; also clears the per-frame counters ----------------------------------------
+__global__ void __launch_bounds__(256) thresholds_kernel(int h, int w, unsigned* __restrict__ hist,
+                                                         double* __restrict__ thr, int* __restrict__ rowcnt,
+                                                         int* __restrict__ npts, int* __restrict__ nseg) {
+    __shared__ unsigned hh[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    hh[tid] = hist[(size_t)s * 256 + tid];
+    hist[(size_t)s * 256 + tid] = 0;                    // ready for the next frame
+    for (int i = tid; i < h; i += 256) rowcnt[(size_t)s * h + i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const long long n = (long long)h * w, k1 = (n - 1) / 2, k2 = n / 2;
+        long long c = 0;
+        int v1 = -1, v2 = -1;
+        for (int v = 0; v < 256; ++v) {
+            c += hh[v];
+            if (v1 < 0 && c > k1) v1 = v;
+            if (v2 < 0 && c > k2) { v2 = v; break; }
+        }
+        const double med = ((double)v1 + (double)v2) / 2.0;          // np.median, even count
+        const double l = 0.7 * med, u = 1.3 * med;
+        double* o = thr + (size_t)s * 4;
+        o[0] = (double)(int)(l > 0.0 ? l : 0.0);                      // int(max(0, 0.7*median))   :80
+        o[1] = (double)(int)(u < 255.0 ? u : 255.0);                  // int(min(255, 1.3*median)) :81
+        o[2] = med;
+        npts[s] = 0, nseg[s] = 0;
+    }
+}
+
+// ---- L2b: Sobel + NMS -> map, union-find seeds ----------------------------------------------------------------
+__global__ void __launch_bounds__(256) sobel_nms_kernel(const uint8_t* __restrict__ blur, int h, int w,
+                                                        const double* __restrict__ thr, uint8_t* __restrict__ map,
+                                                        unsigned* __restrict__ labels) {
+    __shared__ uint8_t b[TH + 4][TW + 4 + 4];
+    __shared__ short gx[TH + 2][TW + 2], gy[TH + 2][TW + 2];
+    __shared__ unsigned short mg[TH + 2][TW + 2];
+    const int s = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const uint8_t* img = blur + (size_t)s * h * w;
+    int lo = (int)thr[(size_t)s * 4], hi = (int)thr[(size_t)s * 4 + 1];
+    if (lo > hi) { const int q = lo; lo = hi; hi = q; }
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int r = i / (TW + 4), c = i - r * (TW + 4);
+        b[r][c] = img[(size_t)clampi(y0 + r - 2, h) * w + clampi(x0 + c - 2, w)];      // BORDER_REPLICATE
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int r = i / (TW + 2), c = i - r * (TW + 2);         // image position (y0 + r - 1, x0 + c - 1)
+        const int yy = y0 + r - 1, xx = x0 + c - 1;
+        const int a00 = b[r][c], a01 = b[r][c + 1], a02 = b[r][c + 2];
+        const int a10 = b[r + 1][c], a12 = b[r + 1][c + 2];
+        const int a20 = b[r + 2][c], a21 = b[r + 2][c + 1], a22 = b[r + 2][c + 2];
+        const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+        const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+        const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        gx[r][c] = (short)dx, gy[r][c] = (short)dy;
+        mg[r][c] = inside ? (unsigned short)(abs(dx) + abs(dy)) : 0;   // magnitude is 0 outside the image
+    }
+    __syncthreads();
+    const int r = tid >> 3, c0 = (tid & 7) * 16;
+    const int y = y0 + r;
+    if (y >= h) return;
+    uint8_t o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + k, rr = r + 1, cc = c + 1;
+        const int m = mg[rr][cc];
+        int v = 1;
+        if (m > lo) {
+            const int xs = gx[rr][cc], ys = gy[rr][cc];
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;
+            bool is_max;
+            if (ay < tg22x) is_max = m > mg[rr][cc - 1] && m >= mg[rr][cc + 1];
+            else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) is_max = m > mg[rr - 1][cc] && m >= mg[rr + 1][cc];
+                else {
+                    const int sg = (xs ^ ys) < 0 ? -1 : 1;
+                    is_max = m > mg[rr - 1][cc - sg] && m > mg[rr + 1][cc + sg];
+                }
+            }
+            if (is_max) v = m > hi ? 2 : 0;
+        }
+        o[k] = (uint8_t)v;
+        const int x = x0 + c;
+        if (v != 1 && x < w) {
+            const unsigned idx = (unsigned)(y * w + x);
+            labels[(size_t)s * h * w + idx] = v == 2 ? idx : (idx | 0x80000000u);   // strong labels sort first
+        }
+    }
+    uint8_t* dst = map + ((size_t)s * h + y) * w + x0 + c0;
+    if (x0 + c0 + 16 <= w && (((size_t)dst) & 15) == 0) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+    else
+        for (int k = 0; k < 16; ++k)
+            if (x0 + c0 + k < w) dst[k] = o[k];
+}
+
+// ---- L2c: hysteresis as connected components -------------------------------------------------------------------
+__device__ __forceinline__ unsigned uf_find(unsigned* lab, unsigned v) {      // v, result: label values
+    unsigned i = v & 0x7fffffffu;
+    unsigned cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((cur & 0x7fffffffu) != i) {
+        i = cur & 0x7fffffffu;
+        cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return cur;
+}
+__device__ __forceinline__ void uf_union(unsigned* lab, unsigned a, unsigned b) {
+    for (;;) {
+        unsigned ra = uf_find(lab, a), rb = uf_find(lab, b);
+        if (ra == rb) return;
+        if (ra < rb) { const unsigned q = ra; ra = rb; rb = q; }             // ra: larger label value
+        const unsigned old = atomicMin(&lab[ra & 0x7fffffffu], rb);
+        if (old == ra) return;
+        a = old, b = rb;
+    }
+}
+
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ map, int h, int w,
+                                                        unsigned* __restrict__ labels) {
+    const int s = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint8_t* m = map + (size_t)s * h * w;
+    unsigned* lab = labels + (size_t)s * h * w;
+    if (m[(size_t)y * w + x] == 1) return;
+    const unsigned me = (unsigned)(y * w + x);
+    if (x > 0 && m[(size_t)y * w + x - 1] != 1) uf_union(lab, me, me - 1);
+    if (y > 0) {
+        const size_t up = (size_t)(y - 1) * w;
+        if (x > 0 && m[up + x - 1] != 1) uf_union(lab, me, (unsigned)(up + x - 1));
+        if (m[up + x] != 1) uf_union(lab, me, (unsigned)(up + x));
+        if (x + 1 < w && m[up + x + 1] != 1) uf_union(lab, me, (unsigned)(up + x + 1));
+    }
+}
+
+struct Roi {
+    int x0, x1, x2, x3, yt;
+};
+__device__ __forceinline__ void roi_bounds(const Roi& r, int h, int y, const int* rows, int& xl, int& xr) {
+    if (rows) { xl = rows[2 * y], xr = rows[2 * y + 1]; return; }
+    if (y < r.yt || y >= h) { xl = 1, xr = 0; return; }
+    const long long den = h - r.yt, t = h - y;
+    xl = (int)((2 * (r.x0 * den + (long long)(r.x1 - r.x0) * t) + den) / (2 * den));
+    xr = (int)((2 * (r.x3 * den + (long long)(r.x2 - r.x3) * t) + den) / (2 * den));
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(const uint8_t* __restrict__ map, int h, int w,
+                                                       unsigned* __restrict__ labels, Roi roi,
+                                                       const int* __restrict__ roi_rows, uint8_t* __restrict__ edges,
+                                                       uint8_t* __restrict__ masked, int* __restrict__ rowcnt) {
+    const int s = blockIdx.z, y = blockIdx.y, tid = threadIdx.x;
+    const uint8_t* m = map + ((size_t)s * h + y) * w;
+    unsigned* lab = labels + (size_t)s * h * w;
+    int xl, xr;
+    roi_bounds(roi, h, y, roi_rows, xl, xr);
+    int cnt = 0;
+    for (int x = blockIdx.x * 1024 + tid * 4; x < w && x < (int)(blockIdx.x + 1) * 1024; x += 1024) {
+        uint8_t e[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = x + q;
+            if (xx < w && m[xx] != 1) {
+                const unsigned root = uf_find(lab, (unsigned)(y * w + xx));
+                if (!(root >> 31)) {
+                    e[q] = 255;
+                    if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
+                }
+            }
+        }
+        const size_t off = ((size_t)s * h + y) * w + x;
+        if (x + 4 <= w && ((off & 3) == 0)) {
+            if (edges) *reinterpret_cast<uchar4*>(edges + off) = make_uchar4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<uchar4*>(masked + off) = make_uchar4(k[0], k[1], k[2], k[3]);
+        } else {
+            for (int q = 0; q < 4 && x + q < w; ++q) {
+                if (edges) edges[off + q] = e[q];
+                masked[off + q] = k[q];
+            }
+        }
+    }
+    cnt = wave_sum_i(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
+}
+
+// ---- L4a: row-major list of edge points -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict__ masked, int h, int w,
+                                                      const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
+                                                      int* __restrict__ npts) {
+    __shared__ int red[4];
+    __shared__ int base_s;
+    const int s = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int* rc = rowcnt + (size_t)s * h;
+    if (rc[y] == 0 && y != h - 1) return;
+    int part = 0;
+    for (int i = tid; i < y; i += 256) part += rc[i];
+    part = wave_sum_i(part);
+    if (lane == 0) red[wid] = part;
+    __syncthreads();
+    if (tid == 0) base_s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    int base = base_s;
+    if (y == h - 1 && tid == 0) npts[s] = base + rc[y];
+    const uint8_t* row = masked + ((size_t)s * h + y) * w;
+    unsigned* out = nz + (size_t)s * h * w;
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + tid;
+        const bool on = x < w && row[x] != 0;
+        const unsigned long long bal = __ballot(on);
+        __syncthreads();
+        if (lane == 0) red[wid] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int q = 0; q < wid; ++q) off += red[q];
+        const int tot = red[0] + red[1] + red[2] + red[3];
+        if (on) out[base + off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)x | ((unsigned)y << 16);
+        base += tot;
+    }
+}
+
+// ---- L4b: progressive probabilistic Hough (cv::HoughLinesProbabilistic) --------------------------------------
+struct HoughCfg {
+    int threshold, line_length, line_gap, max_segments;
+};
+
+// The mask is rewritten while the kernel runs (lines are erased) and read by other waves of the same
+// workgroup: read it past the vector L1.
+__device__ __forceinline__ bool mask_on(const uint8_t* m, size_t i) {
+    return *reinterpret_cast<const volatile uint8_t*>(m + i) != 0;
+}
+
+__global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ masked, int h, int w, int numrho,
+                                                     HoughCfg cfg, unsigned* __restrict__ nz_all,
+                                                     const int* __restrict__ npts, int* __restrict__ accum_all,
+                                                     const float* __restrict__ trig, int* __restrict__ segs,
+                                                     int* __restrict__ nseg) {
+    __shared__ int w_key[3];
+    __shared__ int sh_pt[2];
+    __shared__ unsigned long long flags[64];           // mask bits of 4096 walk steps
+    __shared__ int ends[2][3];                          // x, y, step index of the line end
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint8_t* mask = masked + (size_t)s * h * w;
+    unsigned* nz = nz_all + (size_t)s * h * w;
+    int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
+    const bool th_on = tid < NUMANGLE;
+    const float ct = th_on ? trig[2 * tid] : 0.f, sn = th_on ? trig[2 * tid + 1] : 0.f;
+    int* arow = accum + (size_t)(th_on ? tid : 0) * numrho + (numrho - 1) / 2;
+    unsigned long long rng = ~0ull;
+    int nlines = 0;
+    const int shift = 16;
+    for (int count = npts[s]; count > 0; --count) {
+        if (tid == 0) {
+            // every thread could do this redundantly; one lane keeps the list traffic minimal
+        }
+        rng = (unsigned long long)(unsigned)rng * 4164903690ull + (unsigned)(rng >> 32);
+        const int idx = (int)((unsigned)rng % (unsigned)count);
+        if (tid == 0) {
+            const unsigned p = nz[idx];
+            nz[idx] = nz[count - 1];
+            sh_pt[0] = (int)(p & 0xffffu), sh_pt[1] = (int)(p >> 16);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __syncthreads();
+        const int j = sh_pt[0], i = sh_pt[1];
+        const bool alive = mask_on(mask, (size_t)i * w + j);
+        __syncthreads();
+        if (!alive) continue;
+        // vote: lane = theta
+        int key = -1;
+        if (th_on) {
+            const int r = __float2int_rn((float)j * ct + (float)i * sn);
+            const int val = atomicAdd(&arow[r], 1) + 1;
+            key = (val << 8) | (255 - tid);               // max value, then the smallest theta
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) w_key[wid] = key;
+        __syncthreads();
+        int best = w_key[0] > w_key[1] ? w_key[0] : w_key[1];
+        best = best > w_key[2] ? best : w_key[2];
+        __syncthreads();
+        const int max_val = best >> 8, max_n = 255 - (best & 255);
+        if (max_val < cfg.threshold) continue;
+
+        // walk along the line in both directions
+        const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
+        int x0 = j, y0 = i, dx0, dy0, xflag;
+        if (fabsf(a) > fabsf(b)) {
+            xflag = 1;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(b * (float)(1 << shift) / fabsf(a));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = 0;
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = __float2int_rn(a * (float)(1 << shift) / fabsf(b));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        if (tid < 6) ends[tid / 3][tid % 3] = 0;
+        __syncthreads();
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            // steps are examined 192 at a time; one lane then replays the gap logic over the flag bits
+            int gap = 0, ex = 0, ey = 0, et = 0;
+            bool have = false, done = false;
+            for (int t0 = 0; !done; t0 += 192) {
+                const int t = t0 + tid;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                const bool on = inb && mask_on(mask, (size_t)i1 * w + j1);
+                const unsigned long long bon = __ballot(on), bin = __ballot(inb);
+                if (lane == 0) flags[wid] = bon, flags[4 + wid] = bin;
+                __syncthreads();
+                // uniform replay (every thread runs it; cheap and keeps control flow convergent)
+                for (int q = 0; q < 192 && !done; ++q) {
+                    const unsigned long long fo = flags[q >> 6], fi = flags[4 + (q >> 6)];
+                    if (!((fi >> (q & 63)) & 1ull)) { done = true; break; }
+                    if ((fo >> (q & 63)) & 1ull) {
+                        gap = 0;
+                        const int tt = t0 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
+                        if (xflag) ex = xx, ey = yy >> shift; else ex = xx >> shift, ey = yy;
+                        et = tt;
+                        have = true;
+                    } else if (++gap > cfg.line_gap) { done = true; break; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && have) ends[k][0] = ex, ends[k][1] = ey, ends[k][2] = et;
+        }
+        __syncthreads();
+        const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
+        const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
+        // erase the line's pixels from the mask (start .. line end, both directions); un-vote them if the
+        // line is kept.  192 steps per round: every lane clears its own pixel, then all theta lanes
+        // subtract the votes of each pixel that was on (atomics: no ordering needed between pixels).
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            const int tend = ends[k][2];
+            for (int t0 = 0; t0 <= tend; t0 += 192) {
+                const int t = t0 + tid;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool on = t <= tend && mask_on(mask, (size_t)i1 * w + j1);
+                if (on) mask[(size_t)i1 * w + j1] = 0;
+                const unsigned long long bon = __ballot(on);
+                if (lane == 0) flags[wid] = bon;
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // the cleared bytes are out before anyone re-reads
+                __syncthreads();
+                if (good && th_on) {
+                    for (int wq = 0; wq < 3; ++wq) {
+                        unsigned long long bits = flags[wq];
+                        while (bits) {
+                            const int q = __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int tt = t0 + wq * 64 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
+                            int ii, jj;
+                            if (xflag) jj = xx, ii = yy >> shift; else jj = xx >> shift, ii = yy;
+                            atomicSub(&arow[__float2int_rn((float)jj * ct + (float)ii * sn)], 1);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (good) {
+            if (tid == 0) {
+                int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
+                o[0] = e0x, o[1] = e0y, o[2] = e1x, o[3] = e1y;
+            }
+            if (++nlines >= cfg.max_segments) break;
+        }
+    }
+    if (tid == 0) nseg[s] = nlines;
+}
+
+// ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
+__device__ void jacobi3(double A[3][3], double V[3][3]) {        // symmetric eigen-decomposition, A -> diag
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) V[r][c] = r == c ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq, A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk, A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq, V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// one thread per (stream, side)
+__global__ void lane_fit_kernel(int S, int h, int w, int max_segments, double smoothing, const int* __restrict__ segs,
+                                const int* __restrict__ nseg, double* __restrict__ lane_state,
+                                double* __restrict__ poly, int* __restrict__ pts, int* __restrict__ info,
+                                double* __restrict__ conf, const double* __restrict__ thr, const int* __restrict__ npts) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= S * 2) return;
+    const int s = id >> 1, side = id & 1;
+    const int n = nseg[s];
+    const int* sg = segs + (size_t)s * max_segments * 4;
+    const double cx = (double)w / 2.0;
+    // lstsq on the Vandermonde matrix [y^2 y 1] with numpy.polyfit's column scaling
+    double s4 = 0, s3 = 0, s2 = 0, s1 = 0, s0 = 0, t2 = 0, t1 = 0, t0 = 0;
+    int nl = 0;
+    for (int k = 0; k < n; ++k) {
+        const int x1 = sg[4 * k], y1 = sg[4 * k + 1], x2 = sg[4 * k + 2], y2 = sg[4 * k + 3];
+        if (x2 == x1) continue;                                          // :116-117
+        const double slope = (double)(y2 - y1) / (double)(x2 - x1);
+        if (fabs(slope) < 0.3) continue;                                 // :122-123
+        const double mid = (double)(x1 + x2) / 2.0;
+        const bool is_left = slope < 0 && mid < cx, is_right = slope > 0 && mid > cx;
+        if ((side == 0 && !is_left) || (side == 1 && !is_right)) continue;
+        ++nl;
+        for (int e = 0; e < 2; ++e) {
+            const double y = e ? y2 : y1, x = e ? x2 : x1;
+            const double yy = y * y;
+            s4 += yy * yy, s3 += yy * y, s2 += yy, s1 += y, s0 += 1.0;
+            t2 += yy * x, t1 += y * x, t0 += x;
+        }
+    }
+    double* st = lane_state + (size_t)s * 8 + side * 4;                  // c2 c1 c0 has_prev
+    int* inf = info + (size_t)s * 8;
+    if (side == 0) {
+        inf[4] = n, inf[5] = npts[s], inf[6] = (int)thr[(size_t)s * 4], inf[7] = (int)thr[(size_t)s * 4 + 1];
+    }
+    inf[side] = 0, inf[2 + side] = nl;
+    conf[(size_t)s * 2 + side] = 0.0;
+    if (nl == 0) return;
+    // scaled normal equations G = D^-1 A^T A D^-1, D = column norms (numpy: lhs /= scale)
+    const double d0 = sqrt(s4), d1 = sqrt(s2), d2 = sqrt(s0);
+    double G[3][3] = {{1.0, s3 / (d0 * d1), s2 / (d0 * d2)}, {s3 / (d0 * d1), 1.0, s1 / (d1 * d2)},
+                      {s2 / (d0 * d2), s1 / (d1 * d2), 1.0}};
+    if (d0 == 0.0) G[0][0] = 0.0, G[0][1] = G[1][0] = G[0][2] = G[2][0] = 0.0;
+    if (d1 == 0.0) G[1][1] = 0.0, G[0][1] = G[1][0] = G[1][2] = G[2][1] = 0.0;
+    const double rhs[3] = {d0 > 0 ? t2 / d0 : 0.0, d1 > 0 ? t1 / d1 : 0.0, t0 / d2};
+    double V[3][3];
+    jacobi3(G, V);
+    double lmax = fmax(G[0][0], fmax(G[1][1], G[2][2]));
+    const double rcond = (double)(2 * nl) * 2.220446049250313e-16;       // len(x) * eps
+    double sol[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        const double lam = G[k][k];
+        // lstsq drops singular values <= rcond * s_max.  Working on the Gram matrix squares the spectrum, so
+        // an exactly dependent direction shows up as |lambda| ~ eps * lambda_max rather than 0: anything below
+        // 1e-12 * lambda_max (singular value ratio 1e-6) is treated as dependent as well.
+        if (!(lam > 1e-12 * lmax) || sqrt(lam) <= rcond * sqrt(lmax)) continue;
+        const double proj = (V[0][k] * rhs[0] + V[1][k] * rhs[1] + V[2][k] * rhs[2]) / lam;
+        for (int r = 0; r < 3; ++r) sol[r] += V[r][k] * proj;
+    }
+    double c2 = d0 > 0 ? sol[0] / d0 : 0.0, c1 = d1 > 0 ? sol[1] / d1 : 0.0, c0 = sol[2] / d2;
+    if (st[3] != 0.0) {                                                  // :159-161
+        c2 = smoothing * st[0] + (1.0 - smoothing) * c2;
+        c1 = smoothing * st[1] + (1.0 - smoothing) * c1;
+        c0 = smoothing * st[2] + (1.0 - smoothing) * c0;
+    }
+    st[0] = c2, st[1] = c1, st[2] = c0, st[3] = 1.0;
+    double* po = poly + ((size_t)s * 2 + side) * 3;
+    po[0] = c2, po[1] = c1, po[2] = c0;
+    // np.linspace(h*0.6, h, 50); np.polyval (Horner); astype(int32) truncates toward zero
+    const double ya = (double)h * 0.6, yb = (double)h, step = (yb - ya) / 49.0;
+    int* pp = pts + ((size_t)s * 2 + side) * 100;
+    for (int k = 0; k < 50; ++k) {
+        const double y = k == 49 ? yb : (double)k * step + ya;
+        const double x = (c2 * y + c1) * y + c0;
+        pp[2 * k] = (int)x, pp[2 * k + 1] = (int)y;
+    }
+    inf[side] = 1;
+    conf[(size_t)s * 2 + side] = fmin(1.0, (double)nl / 10.0);          // :172
+}
+
+struct LaneCtx {
+    float* d_trig = nullptr;
+};
+
+}  // namespace
+
+extern "C" {
+
+int av_lane_ctx_free(av_ctx* ctx) {
+    if (ctx && ctx->lane) {
+        LaneCtx* lc = (LaneCtx*)ctx->lane;
+        if (lc->d_trig) (void)hipFree(lc->d_trig);
+        delete lc;
+        ctx->lane = nullptr;
+    }
+    return AV_OK;
+}
+
+size_t av_lane_workspace_bytes(int n_streams, int h, int w, int max_segments) {
+    if (n_streams <= 0 || h <= 0 || w <= 0 || max_segments <= 0) return 0;
+    return lane_layout(n_streams, h, w, max_segments).total;
+}
+
+int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segments, size_t* offset, size_t* bytes) {
+    AV_REQUIRE(offset && bytes, AV_EINVAL, "av_lane_workspace_view: null out pointer");
+    const LaneWs L = lane_layout(n_streams, h, w, max_segments);
+    const size_t px = (size_t)n_streams * h * w;
+    switch (what) {
+        case 0: *offset = L.blur, *bytes = px; break;
+        case 1: *offset = L.map, *bytes = px; break;
+        case 2: *offset = L.edges, *bytes = px; break;
+        case 3: *offset = L.masked, *bytes = px; break;
+        case 4: *offset = L.thr, *bytes = (size_t)n_streams * 32; break;
+        case 5: *offset = L.segs, *bytes = (size_t)n_streams * max_segments * 16; break;
+        case 6: *offset = L.nseg, *bytes = (size_t)n_streams * 4; break;
+        case 7: *offset = L.accum, *bytes = (size_t)n_streams * NUMANGLE * L.numrho * 4; break;
+        default: av_set_error("av_lane_workspace_view: unknown view %d", what); return AV_EINVAL;
+    }
+    return AV_OK;
+}
+
+int av_lane_workspace_init(av_ctx* ctx, av_stream_t stream, int n_streams, int h, int w, int max_segments, void* ws) {
+    AV_REQUIRE(ctx && ws, AV_EINVAL, "av_lane_workspace_init: null argument");
+    const LaneWs L = lane_layout(n_streams, h, w, max_segments);
+    AV_HIP(hipMemsetAsync(ws, 0, L.total, as_stream(stream)));     // histogram, accumulator start at zero
+    return AV_OK;
+}
+
+int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int n_streams, int h, int w,
+                   const uint8_t* bgr, const int32_t* roi_rows, void* workspace, double* lane_state, double* poly,
+                   int32_t* pts, int32_t* info, double* conf, int stages) {
+    AV_REQUIRE(ctx && cfg && bgr && workspace && lane_state && poly && pts && info && conf, AV_EINVAL,
+               "av_lane_detect: null argument");
+    AV_REQUIRE(n_streams > 0 && h >= 8 && w >= 8 && h < 32768 && w < 32768, AV_EINVAL, "av_lane_detect: bad frame size %dx%d", w, h);
+    AV_REQUIRE(cfg->max_segments > 0 && cfg->hough_threshold > 0, AV_EINVAL, "av_lane_detect: bad configuration");
+    AV_REQUIRE((size_t)h * w < (1u << 31), AV_EINVAL, "av_lane_detect: frame too large for 31-bit labels");
+    hipStream_t st = as_stream(stream);
+    if (!ctx->lane) {
+        // trig table of cv::HoughLinesProbabilistic: theta is a float, angles n*theta in double
+        LaneCtx* lc = new (std::nothrow) LaneCtx();
+        AV_REQUIRE(lc, AV_ENOMEM, "av_lane_detect: out of host memory");
+        float tt[2 * NUMANGLE];
+        const float theta = (float)(3.14159265358979323846 / 180.0);
+        for (int n = 0; n < NUMANGLE; ++n) {
+            tt[2 * n] = (float)(std::cos((double)n * theta) * 1.0f);
+            tt[2 * n + 1] = (float)(std::sin((double)n * theta) * 1.0f);
+        }
+        AV_HIP(hipMalloc(&lc->d_trig, sizeof(tt)));
+        AV_HIP(hipMemcpy(lc->d_trig, tt, sizeof(tt), hipMemcpyHostToDevice));
+        ctx->lane = lc;
+    }
+    LaneCtx* lc = (LaneCtx*)ctx->lane;
+    const LaneWs L = lane_layout(n_streams, h, w, cfg->max_segments);
+    unsigned char* ws = (unsigned char*)workspace;
+    uint8_t* blur = ws + L.blur;
+    uint8_t* map = ws + L.map;
+    unsigned* labels = (unsigned*)(ws + L.labels);
+    uint8_t* edges = ws + L.edges;
+    uint8_t* masked = ws + L.masked;
+    unsigned* hist = (unsigned*)(ws + L.hist);
+    double* thr = (double*)(ws + L.thr);
+    int* rowcnt = (int*)(ws + L.rowcnt);
+    unsigned* nz = (unsigned*)(ws + L.nz);
+    int* npts = (int*)(ws + L.npts);
+    int* accum = (int*)(ws + L.accum);
+    int* segs = (int*)(ws + L.segs);
+    int* nseg = (int*)(ws + L.nseg);
+    const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
+    hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
+    AV_LAUNCH_CHECK();
+    Roi roi;
+    roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
+    roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
+    hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
+                       roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
+    AV_LAUNCH_CHECK();
+    if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)
+    HoughCfg hc{cfg->hough_threshold, cfg->min_line_length, cfg->max_line_gap, cfg->max_segments};
+    hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
+                       lc->d_trig, segs, nseg);
+    AV_LAUNCH_CHECK();
+    // the accumulator must be all zeros again for the next frame (PPHT leaves residual and negative votes)
+    AV_HIP(hipMemsetAsync(accum, 0, (size_t)n_streams * NUMANGLE * L.numrho * 4, st));
+    hipLaunchKernelGGL(lane_fit_kernel, dim3((n_streams * 2 + 63) / 64), dim3(64), 0, st, n_streams, h, w,
+                       cfg->max_segments, cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // extern "C"

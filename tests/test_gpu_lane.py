@@ -1,0 +1,75 @@
+"""Lane pixel path: HIP kernels vs the C/NumPy oracle (OpenCV semantics restated; parity unpinned)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def LaneDetector():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    from src.perception import LaneDetector
+    return LaneDetector
+
+
+def _frames():
+    from oracle.lane_ref import synthetic_frame
+    rng = np.random.RandomState(5)
+    noise = rng.randint(0, 256, size=(96, 200, 3)).astype(np.uint8)
+    return [("synthetic720", synthetic_frame(720, 1280, 0, 0)), ("synthetic480", synthetic_frame(480, 640, 3, 7)),
+            ("odd_size", synthetic_frame(250, 333, 1, 2)), ("noise", noise),
+            ("flat", np.full((64, 80, 3), 90, np.uint8))]
+
+
+@pytest.mark.parametrize("name,frame", _frames(), ids=[n for n, _ in _frames()])
+def test_pixel_stages_bit_exact(LaneDetector, name, frame):
+    from oracle.lane_ref import LaneRef
+    want = LaneRef().stages(frame)
+    det = LaneDetector()
+    det._run(frame, stages=3)                  # pixel stages only, keep the pre-ROI edge map
+    h, w = frame.shape[:2]
+    assert np.array_equal(det._view(0, np.uint8, (h, w)), want["blur"])
+    thr = det._view(4, np.float64, (4,))
+    assert (thr[0], thr[1], thr[2]) == (want["lo"], want["hi"], want["median"])
+    assert np.array_equal(det._view(2, np.uint8, (h, w)), want["edges"])
+    assert np.array_equal(det._view(3, np.uint8, (h, w)), want["masked"])
+
+
+@pytest.mark.parametrize("name,frame", _frames()[:3], ids=[n for n, _ in _frames()[:3]])
+def test_hough_segments_and_fit(LaneDetector, name, frame):
+    from oracle.lane_ref import LaneRef
+    ref = LaneRef()
+    det = LaneDetector()
+    for rep in range(3):                       # EMA state carries across frames
+        want = ref.detect(frame)
+        left, right = det.detect(frame)
+        segs = det._view(5, np.int32, (det.MAX_SEGMENTS, 4))[:int(det._view(6, np.int32, (1,))[0])]
+        assert np.array_equal(segs, want["segments"]), "segments differ (rep %d)" % rep
+        for got, exp in ((left, want["left"]), (right, want["right"])):
+            assert (got is None) == (exp is None)
+            if got is None:
+                continue
+            pts, conf, co = exp
+            np.testing.assert_allclose(got.polynomial, co, rtol=1e-6, atol=1e-6)
+            assert got.confidence == conf
+            assert np.abs(got.points - pts).max() <= 1
+            assert got.points.dtype == np.int32 and got.points.shape == (50, 2)
+    if left is not None and right is not None:
+        assert left.side == "left" and right.side == "right"
+        np.testing.assert_allclose(det.prev_left_fit, ref.prev_left, rtol=1e-6, atol=1e-6)
+        off = det.get_lane_center_offset(frame.shape[1], left, right)
+        assert off == frame.shape[1] / 2 - (left.points[-1, 0] + right.points[-1, 0]) / 2
+    else:
+        assert name == "odd_size"
+    det.reset()
+    assert det.prev_left_fit is None and det.prev_right_fit is None
+
+
+def test_no_lanes_on_flat_frame(LaneDetector):
+    det = LaneDetector()
+    assert det.detect(np.full((120, 160, 3), 77, np.uint8)) == (None, None)
+    assert det.get_lane_center_offset(160, None, None) is None
+    with pytest.raises(ValueError):
+        det.detect(np.zeros((10, 10), np.uint8))
