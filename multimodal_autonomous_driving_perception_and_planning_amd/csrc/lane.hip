@@ -290,6 +290,212 @@ __global__ void __launch_bounds__(256) finalize_kernel(const uint8_t* __restrict
     if ((tid & 63) == 0 && cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
 }
 
+// ===== fast paths (w % 16 == 0, 16-byte aligned frames): every global access is a 16-byte vector ===========
+
+// 16 sub-histograms (lane & 15) cut same-bin LDS-atomic conflicts from 64-way to 4-way on flat image areas.
+__device__ __forceinline__ void hist_add(unsigned* lh16, int lane, int v, unsigned n) {
+    atomicAdd(&lh16[(lane & 15) * 256 + v], n);
+}
+
+__global__ void __launch_bounds__(256) gray_blur_hist_fast(const uint8_t* __restrict__ bgr, int h, int w,
+                                                           uint8_t* __restrict__ blur, unsigned* __restrict__ hist) {
+    constexpr int RAWB = 432;                               // >= (TW + 4) * 3 + 15, multiple of 16
+    __shared__ __attribute__((aligned(16))) uint8_t raw[TH + 4][RAWB];
+    __shared__ uint8_t g[TH + 4][TW + 8];
+    __shared__ unsigned short t[TH + 4][TW];
+    __shared__ unsigned lh[16 * 256];
+    const int s = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x, lane = tid & 63;
+    const uint8_t* img = bgr + (size_t)s * h * w * 3;
+    for (int i = tid; i < 16 * 256; i += 256) lh[i] = 0;
+    // in-image column range this tile needs, as a 16-byte aligned byte range of the row
+    const int cxa = x0 - 2 < 0 ? 0 : x0 - 2, cxb = x0 + TW + 2 > w ? w : x0 + TW + 2;
+    const int b0 = (cxa * 3) & ~15, b1 = (cxb * 3 + 15) & ~15;          // w*3 % 16 == 0 -> b1 <= row bytes
+    const int nch = (b1 - b0) >> 4;
+    for (int i = tid; i < (TH + 4) * nch; i += 256) {
+        const int r = i / nch, c = i - r * nch;
+        const int yy = reflect101(y0 + r - 2, h);
+        *reinterpret_cast<uint4*>(&raw[r][c * 16]) =
+            *reinterpret_cast<const uint4*>(img + (size_t)yy * w * 3 + b0 + c * 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int r = i / (TW + 4), c = i - r * (TW + 4);
+        const int xx = reflect101(x0 + c - 2, w);
+        const uint8_t* p = &raw[r][xx * 3 - b0];
+        g[r][c] = (uint8_t)((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14);
+    }
+    __syncthreads();
+    for (int i = tid; i < (TH + 4) * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        t[r][c] = (unsigned short)(g[r][c] + 4 * g[r][c + 1] + 6 * g[r][c + 2] + 4 * g[r][c + 3] + g[r][c + 4]);
+    }
+    __syncthreads();
+    const int r = tid >> 3, c0 = (tid & 7) * 16;
+    const int y = y0 + r;
+    if (y < h && x0 + c0 < w) {
+        uint8_t o[16];
+        int run_v = -1;
+        unsigned run_n = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = c0 + k;
+            const int v = (t[r][c] + 4 * t[r + 1][c] + 6 * t[r + 2][c] + 4 * t[r + 3][c] + t[r + 4][c] + 128) >> 8;
+            o[k] = (uint8_t)v;
+            if (v == run_v) ++run_n;
+            else {
+                if (run_n) hist_add(lh, lane, run_v, run_n);
+                run_v = v, run_n = 1;
+            }
+        }
+        hist_add(lh, lane, run_v, run_n);
+        *reinterpret_cast<uint4*>(blur + ((size_t)s * h + y) * w + x0 + c0) = *reinterpret_cast<const uint4*>(o);
+    }
+    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += lh[q * 256 + tid];
+    if (tot) atomicAdd(&hist[(size_t)s * 256 + tid], tot);
+}
+
+__global__ void __launch_bounds__(256) sobel_nms_fast(const uint8_t* __restrict__ blur, int h, int w,
+                                                      const double* __restrict__ thr, uint8_t* __restrict__ map,
+                                                      unsigned* __restrict__ labels) {
+    constexpr int RB = TW + 32;                              // tile row bytes incl. 16-byte aligned halo
+    __shared__ __attribute__((aligned(16))) uint8_t b[TH + 4][RB];
+    __shared__ short gx[TH + 2][TW + 2], gy[TH + 2][TW + 2];
+    __shared__ unsigned short mg[TH + 2][TW + 2];
+    const int s = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, tid = threadIdx.x;
+    const uint8_t* img = blur + (size_t)s * h * w;
+    int lo = (int)thr[(size_t)s * 4], hi = (int)thr[(size_t)s * 4 + 1];
+    if (lo > hi) { const int q = lo; lo = hi; hi = q; }
+    // b[r][16 + c] holds image column x0 + c; chunks x0-16 .. x0+TW+15 (clamped chunks duplicate the border)
+    constexpr int NCH = RB / 16;
+    for (int i = tid; i < (TH + 4) * NCH; i += 256) {
+        const int r = i / NCH, c = i - r * NCH;
+        const int yy = clampi(y0 + r - 2, h);
+        int xs = x0 - 16 + c * 16;
+        xs = xs < 0 ? 0 : (xs > w - 16 ? w - 16 : xs);
+        *reinterpret_cast<uint4*>(&b[r][c * 16]) = *reinterpret_cast<const uint4*>(img + (size_t)yy * w + xs);
+    }
+    __syncthreads();
+    auto px = [&](int r, int xx) -> int {                     // BORDER_REPLICATE column lookup inside the tile
+        const int xc = clampi(xx, w);
+        int off = xc - x0 + 16;
+        if (x0 == 0 && off < 16) off = xc + 16;               // left chunk was clamped to columns 0..15
+        if (x0 + TW >= w && off >= 16 + TW) off = xc - (w - 16) + 16 + TW;   // right chunk clamped to w-16..w-1
+        return b[r][off];
+    };
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int r = i / (TW + 2), c = i - r * (TW + 2);
+        const int yy = y0 + r - 1, xx = x0 + c - 1;
+        const int a00 = px(r, xx - 1), a01 = px(r, xx), a02 = px(r, xx + 1);
+        const int a10 = px(r + 1, xx - 1), a12 = px(r + 1, xx + 1);
+        const int a20 = px(r + 2, xx - 1), a21 = px(r + 2, xx), a22 = px(r + 2, xx + 1);
+        const int dx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+        const int dy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+        const bool inside = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        gx[r][c] = (short)dx, gy[r][c] = (short)dy;
+        mg[r][c] = inside ? (unsigned short)(abs(dx) + abs(dy)) : 0;
+    }
+    __syncthreads();
+    const int r = tid >> 3, c0 = (tid & 7) * 16;
+    const int y = y0 + r;
+    if (y >= h || x0 + c0 >= w) return;
+    uint8_t o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + k, rr = r + 1, cc = c + 1;
+        const int m = mg[rr][cc];
+        int v = 1;
+        if (m > lo) {
+            const int xs = gx[rr][cc], ys = gy[rr][cc];
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;
+            bool is_max;
+            if (ay < tg22x) is_max = m > mg[rr][cc - 1] && m >= mg[rr][cc + 1];
+            else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) is_max = m > mg[rr - 1][cc] && m >= mg[rr + 1][cc];
+                else {
+                    const int sg = (xs ^ ys) < 0 ? -1 : 1;
+                    is_max = m > mg[rr - 1][cc - sg] && m > mg[rr + 1][cc + sg];
+                }
+            }
+            if (is_max) v = m > hi ? 2 : 0;
+        }
+        o[k] = (uint8_t)v;
+        if (v != 1) {
+            const unsigned idx = (unsigned)(y * w + x0 + c);
+            labels[(size_t)s * h * w + idx] = v == 2 ? idx : (idx | 0x80000000u);
+        }
+    }
+    *reinterpret_cast<uint4*>(map + ((size_t)s * h + y) * w + x0 + c0) = *reinterpret_cast<const uint4*>(o);
+}
+
+__device__ __forceinline__ bool all_ones16(const uint4& v) {
+    return v.x == 0x01010101u && v.y == 0x01010101u && v.z == 0x01010101u && v.w == 0x01010101u;
+}
+
+// one thread per 16-pixel chunk; chunks without candidates (almost all) cost one 16-byte load
+__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map, int h, int w,
+                                                      unsigned* __restrict__ labels) {
+    const int s = blockIdx.z, cw = w >> 4;
+    const int ci = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (ci >= cw) return;
+    const uint8_t* m = map + (size_t)s * h * w;
+    unsigned* lab = labels + (size_t)s * h * w;
+    const uint4 cur4 = *reinterpret_cast<const uint4*>(m + (size_t)y * w + ci * 16);
+    if (all_ones16(cur4)) return;
+    const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
+    const int xb = ci * 16;
+    for (int k = 0; k < 16; ++k) {
+        if (cur[k] == 1) continue;
+        const int x = xb + k;
+        const unsigned me = (unsigned)(y * w + x);
+        if (x > 0 && (k > 0 ? cur[k - 1] : m[(size_t)y * w + x - 1]) != 1) uf_union(lab, me, me - 1);
+        if (y > 0) {
+            const size_t up = (size_t)(y - 1) * w;
+            if (x > 0 && m[up + x - 1] != 1) uf_union(lab, me, (unsigned)(up + x - 1));
+            if (m[up + x] != 1) uf_union(lab, me, (unsigned)(up + x));
+            if (x + 1 < w && m[up + x + 1] != 1) uf_union(lab, me, (unsigned)(up + x + 1));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map, int h, int w,
+                                                     unsigned* __restrict__ labels, Roi roi,
+                                                     const int* __restrict__ roi_rows, uint8_t* __restrict__ edges,
+                                                     uint8_t* __restrict__ masked, int* __restrict__ rowcnt) {
+    const int s = blockIdx.z, cw = w >> 4;
+    const int ci = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    int cnt = 0;
+    if (ci < cw) {
+        const size_t off = ((size_t)s * h + y) * w + ci * 16;
+        const uint4 cur4 = *reinterpret_cast<const uint4*>(map + off);
+        uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
+        if (!all_ones16(cur4)) {
+            unsigned* lab = labels + (size_t)s * h * w;
+            int xl, xr;
+            roi_bounds(roi, h, y, roi_rows, xl, xr);
+            const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
+            uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
+            uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
+            for (int q = 0; q < 16; ++q) {
+                if (cur[q] == 1) continue;
+                const int xx = ci * 16 + q;
+                if (!(uf_find(lab, (unsigned)(y * w + xx)) >> 31)) {
+                    e[q] = 255;
+                    if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
+                }
+            }
+        }
+        if (edges) *reinterpret_cast<uint4*>(edges + off) = e4;
+        *reinterpret_cast<uint4*>(masked + off) = k4;
+    }
+    cnt = wave_sum_i(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
+}
+
 // ---- L4a: row-major list of edge points -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict__ masked, int h, int w,
                                                       const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
@@ -682,19 +888,28 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* segs = (int*)(ws + L.segs);
     int* nseg = (int*)(ws + L.nseg);
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
-    hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+    const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0;
+    if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+    else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
     AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+    if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+    else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
     AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
+    const dim3 chunks(((w >> 4) + 255) / 256, h, n_streams);
+    if (fastp) hipLaunchKernelGGL(ccl_merge_fast, chunks, dim3(256), 0, st, map, h, w, labels);
+    else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
     AV_LAUNCH_CHECK();
     Roi roi;
     roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
     roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
-    hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
-                       roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
+    if (fastp)
+        hipLaunchKernelGGL(finalize_fast, chunks, dim3(256), 0, st, map, h, w, labels, roi, roi_rows,
+                           (stages & 1) ? edges : nullptr, masked, rowcnt);
+    else
+        hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
+                           roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
     AV_LAUNCH_CHECK();
