@@ -234,6 +234,29 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                    const uint8_t* bgr, const int32_t* roi_rows, void* workspace, double* lane_state,
                    double* poly, int32_t* pts, int32_t* info, double* conf, int stages);
 
+/* ---- D2: YOLO-mode detector ---------------------------------------------------------------------
+ * Replaces ObjectDetector._detect_yolo (src/perception/detector.py:103-123), i.e. ultralytics
+ * YOLO(model)(frame): letterbox -> YOLOv8n graph (Conv/BN/SiLU, C2f, SPPF, Detect+DFL) -> best-class
+ * confidence filter -> class-aware NMS -> boxes scaled back to the frame.  `weights` is a HOST array in
+ * the parameter order documented in perception/yolo.py (per conv: weight[cout][cin][k][k], then BN
+ * gamma, beta, running_mean, running_var or, for the two plain Conv2d of each head branch, bias);
+ * BatchNorm is folded and everything is converted to bf16 at creation.  All activation and NMS scratch
+ * is allocated here, once. */
+typedef struct av_yolo av_yolo;
+size_t av_yolo_param_count(void);
+int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights,
+                   av_yolo** out);
+int av_yolo_destroy(av_yolo* h);
+int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors);        /* host out */
+/*   bgr      u8 [batch][in_h][in_w][3] (device)
+ *   det_n    int32 [batch]; det_box float [batch][max_det][4] xyxy in frame pixels (not truncated);
+ *   det_conf float [batch][max_det]; det_cls int32 [batch][max_det]; rows in descending confidence */
+int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float conf_thres, float iou_thres,
+                    int max_det, int32_t* det_n, float* det_box, float* det_conf, int32_t* det_cls);
+/* Test hook: device pointer + geometry of an intermediate NHWC tensor (bf16; ids = yolov8.yaml layer
+ * numbers, 0 = network input; 100+2i / 101+2i = float32 box / class logits of level i). */
+int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff);
+
 #ifdef __cplusplus
 }
 #endif

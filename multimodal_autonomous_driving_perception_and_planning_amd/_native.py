@@ -80,6 +80,12 @@ _SIGS = [
     ("av_lane_workspace_init", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_lane_workspace_view", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_size_t)]),
+    ("av_yolo_param_count", C.c_size_t, []),
+    ("av_yolo_create", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),
+    ("av_yolo_destroy", C.c_int, [vp]),
+    ("av_yolo_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("av_yolo_forward", C.c_int, [vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),
+    ("av_yolo_tensor", C.c_int, [vp, C.c_int, C.POINTER(vp)] + [C.POINTER(C.c_int)] * 5),
     ("av_lane_detect", C.c_int, [vp, vp, C.POINTER(LaneCfg), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp,
                                  vp, C.c_int]),
 ]

@@ -1,0 +1,613 @@
+// D2: YOLOv8n-topology detector, MFMA convolution path.
+//
+// Reference call site: ObjectDetector._detect_yolo (src/perception/detector.py:103-123) ->
+// ultralytics YOLO("yolov8n.pt")(frame) (third party, not vendored; topology restated in
+// oracle/yolo_ref.py, which also defines the parameter order this file consumes).
+//
+// Layout: activations are NHWC bf16 with an explicit channel stride, so a producer can write straight
+// into a channel slice of a concat buffer (every Concat / chunk of the graph is free) and a consumer can
+// read a slice.  Convolution = implicit GEMM on v_mfma_f32_16x16x32_bf16 with the *weights* as the A
+// operand (rows = output channels) and the gathered input patch as B (columns = output pixels): the
+// accumulator then holds 4 consecutive channels of one pixel per lane, i.e. an 8-byte NHWC store.
+// BatchNorm (eval) is folded into weights/bias on the host; SiLU, the Bottleneck residual and the
+// bf16 conversion are fused into the epilogue.  K = taps*Cin is padded to a multiple of 32; Cin is
+// always a multiple of 8, so one lane's 8-element fragment never straddles a filter tap.
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef unsigned short bf16_t;
+
+constexpr int NC = 80, REG_MAX = 16, MAX_CAND = 8192;
+
+__host__ __device__ inline bf16_t f2bf(float f) {
+    unsigned u;
+#ifdef __HIP_DEVICE_COMPILE__
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ inline float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+
+struct ConvArgs {
+    const bf16_t* in;   int in_cs, in_coff, cin, H, W;        // input NHWC (batch folded into pixels via n)
+    const bf16_t* wgt;  const float* bias; int kpad, kreal, ksz, stride;
+    bf16_t* out;        float* out32; int out_cs, out_coff, cout, Ho, Wo;
+    const bf16_t* res;  int res_cs, res_coff;                 // optional residual (added after the activation)
+    int act, npix;                                            // npix = B*Ho*Wo
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pix_base = (blockIdx.x * 4 + wave) * 16 * NT;
+    const int ch_base = blockIdx.y * 16 * MT;
+    if (pix_base >= a.npix) return;
+    const int l15 = lane & 15, h = lane >> 4, pad = a.ksz >> 1;
+    int iy0[NT], ix0[NT], nb[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = pix_base + nt * 16 + l15;
+        pv[nt] = p < a.npix;
+        const int pp = pv[nt] ? p : 0;
+        const int n = pp / (a.Ho * a.Wo), r = pp - n * a.Ho * a.Wo;
+        const int oy = r / a.Wo, ox = r - oy * a.Wo;
+        iy0[nt] = oy * a.stride - pad, ix0[nt] = ox * a.stride - pad, nb[nt] = n * a.H;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 8 * h, tap = k / a.cin, ci = k - tap * a.cin;
+    const bf16_t* wrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.wgt + (size_t)(ch_base + mt * 16 + l15) * a.kpad + 8 * h;
+    for (int k0 = 0; k0 < a.kpad; k0 += 32) {
+        const int ky = a.ksz == 1 ? 0 : tap / 3, kx = a.ksz == 1 ? 0 : tap - ky * 3;
+        const bool kv = (k0 + 8 * h) < a.kreal;
+        bf16x8 A[MT], B[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const bf16x8*>(wrow[mt] + k0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int iy = iy0[nt] + ky, ix = ix0[nt] + kx;
+            const bool ok = kv && pv[nt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const bf16x8*>(a.in + ((size_t)(nb[nt] + iy) * a.W + ix) * a.in_cs + a.in_coff + ci);
+            B[nt] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+        ci += 32;
+        while (ci >= a.cin) ci -= a.cin, ++tap;
+    }
+    // epilogue: lane holds channels ch_base + mt*16 + 4h + {0..3} of pixel pix_base + nt*16 + l15
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch = ch_base + mt * 16 + 4 * h;
+        const float4 bs = *reinterpret_cast<const float4*>(a.bias + ch);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (!pv[nt]) continue;
+            const size_t p = (size_t)(pix_base + nt * 16 + l15);
+            float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
+            if (a.act)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.0f + __expf(-v[q]));              // SiLU
+            if (a.res) {
+                const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
+                v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
+            }
+            if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                *reinterpret_cast<ushort4*>(a.out + p * a.out_cs + a.out_coff + ch) =
+                    make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+        }
+    }
+}
+
+// letterbox + bilinear resize + BGR->RGB + /255 -> NHWC8 bf16 (channels 3..7 zero)
+__global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
+                                  int top, int left, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int n = i / (H * W), r = i - n * H * W, y = r / W, x = r - y * W;
+    float c[3] = {114.f, 114.f, 114.f};
+    const int yy = y - top, xx = x - left;
+    if (yy >= 0 && yy < nh && xx >= 0 && xx < nw) {
+        const float sy = ((float)yy + 0.5f) * ((float)h / (float)nh) - 0.5f, sx = ((float)xx + 0.5f) * ((float)w / (float)nw) - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float wy = sy - fy, wx = sx - fx;
+        int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0), y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+        x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0), x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+        const uint8_t* im = bgr + (size_t)n * h * w * 3;
+        for (int q = 0; q < 3; ++q) {
+            const float p00 = im[((size_t)y0 * w + x0) * 3 + q], p01 = im[((size_t)y0 * w + x1) * 3 + q];
+            const float p10 = im[((size_t)y1 * w + x0) * 3 + q], p11 = im[((size_t)y1 * w + x1) * 3 + q];
+            const float ta = p00 * (1.f - wx) + p01 * wx, tb = p10 * (1.f - wx) + p11 * wx;
+            c[q] = floorf(ta * (1.f - wy) + tb * wy + 0.5f);
+        }
+    }
+    bf16_t o[8] = {f2bf(c[2] / 255.f), f2bf(c[1] / 255.f), f2bf(c[0] / 255.f), 0, 0, 0, 0, 0};   // RGB
+    *reinterpret_cast<uint4*>(out + (size_t)i * 8) = *reinterpret_cast<const uint4*>(o);
+}
+
+__global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
+                                int H, int W, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W * C) return;
+    const int c = i % C, p = i / C, n = p / (H * W), r = p - n * H * W, y = r / W, x = r - y * W;
+    float m = -INFINITY;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            m = fmaxf(m, bf2f(in[((size_t)(n * H + yy) * W + xx) * cs_in + coff_in + c]));
+        }
+    out[(size_t)p * cs_out + coff_out + c] = f2bf(m);
+}
+
+__global__ void upsample2_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
+                                 int H, int W, int C) {   // H, W: input size; output 2H x 2W, nearest
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = C / 8;
+    if (i >= B * 4 * H * W * C8) return;
+    const int c8 = i % C8, p = i / C8, n = p / (4 * H * W), r = p - n * 4 * H * W, y = r / (2 * W), x = r - y * 2 * W;
+    *reinterpret_cast<uint4*>(out + (size_t)p * cs_out + coff_out + c8 * 8) =
+        *reinterpret_cast<const uint4*>(in + ((size_t)(n * H + (y >> 1)) * W + (x >> 1)) * cs_in + coff_in + c8 * 8);
+}
+
+struct Level { const float* box; const float* cls; int H, W, stride, aoff; };
+
+// DFL expectation + best class; writes candidates of every anchor
+__global__ void decode_kernel(Level l0, Level l1, Level l2, int A, int B, float* __restrict__ cbox, float* __restrict__ cconf,
+                              int* __restrict__ ccls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * A) return;
+    const int n = i / A, a = i - n * A;
+    const Level L = a < l1.aoff ? l0 : (a < l2.aoff ? l1 : l2);
+    const int q = a - L.aoff, y = q / L.W, x = q - y * L.W;
+    const float* bx = L.box + ((size_t)(n * L.H + y) * L.W + x) * 64;
+    float d[4];
+    for (int s = 0; s < 4; ++s) {
+        float mx = -INFINITY;
+        for (int j = 0; j < REG_MAX; ++j) mx = fmaxf(mx, bx[s * REG_MAX + j]);
+        float sum = 0.f, ex = 0.f;
+        for (int j = 0; j < REG_MAX; ++j) {
+            const float e = expf(bx[s * REG_MAX + j] - mx);
+            sum += e, ex += e * (float)j;
+        }
+        d[s] = ex / sum;
+    }
+    const float ax = (float)x + 0.5f, ay = (float)y + 0.5f, st = (float)L.stride;
+    const float* cl = L.cls + ((size_t)(n * L.H + y) * L.W + x) * NC;
+    float best = -INFINITY;
+    int bj = 0;
+    for (int j = 0; j < NC; ++j)
+        if (cl[j] > best) best = cl[j], bj = j;
+    float* o = cbox + (size_t)i * 4;
+    o[0] = (ax - d[0]) * st, o[1] = (ay - d[1]) * st, o[2] = (ax + d[2]) * st, o[3] = (ay + d[3]) * st;
+    cconf[i] = 1.f / (1.f + expf(-best));
+    ccls[i] = bj;
+}
+
+// per image: candidates with conf > thres sorted by (conf desc, anchor asc) -> class-offset boxes
+__global__ void __launch_bounds__(1024) nms_sort_kernel(int A, float conf_thres, const float* __restrict__ cbox,
+                                                        const float* __restrict__ cconf, const int* __restrict__ ccls,
+                                                        float* __restrict__ sbox, int* __restrict__ sidx, int* __restrict__ scount) {
+    __shared__ unsigned long long key[MAX_CAND];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < MAX_CAND; i += 1024) {
+        unsigned long long k = ~0ull;                         // sorts last
+        if (i < A) {
+            const float c = cconf[(size_t)n * A + i];
+            if (c > conf_thres) k = ((unsigned long long)(~__float_as_uint(c)) << 32) | (unsigned)i;   // conf > 0: bits monotone
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int sz = 2; sz <= MAX_CAND; sz <<= 1)
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            for (int i = tid; i < MAX_CAND / 2; i += 1024) {
+                const int lo = (i / st) * 2 * st + (i % st), hi = lo + st;
+                const bool up = ((lo & sz) == 0);
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) key[lo] = b, key[hi] = a;
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < A; i += 1024) {
+        const unsigned long long k = key[i];
+        if (k != ~0ull) {
+            const int a = (int)(unsigned)k;
+            const float off = (float)ccls[(size_t)n * A + a] * 7680.0f;
+            const float* b = cbox + ((size_t)n * A + a) * 4;
+            float* o = sbox + ((size_t)n * A + i) * 4;
+            o[0] = b[0] + off, o[1] = b[1] + off, o[2] = b[2] + off, o[3] = b[3] + off;
+            sidx[(size_t)n * A + i] = a;
+            if (i == A - 1 || key[i + 1] == ~0ull) scount[n] = i + 1;       // valid keys sort first
+        } else if (i == 0) {
+            scount[n] = 0;
+        }
+    }
+}
+
+// 64x64 blocks of the suppression relation as bit masks (torchvision-style)
+__global__ void __launch_bounds__(64) nms_mask_kernel(int A, int words, float iou_thres, const float* __restrict__ sbox,
+                                                      const int* __restrict__ scount, unsigned long long* __restrict__ mask) {
+    const int n = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x, cnt = scount[n];
+    if (rb * 64 >= cnt || cb * 64 >= cnt || cb < rb) return;
+    __shared__ float cbx[64][4];
+    const int t = threadIdx.x;
+    const int cj = cb * 64 + t;
+    if (cj < cnt) {
+        const float* b = sbox + ((size_t)n * A + cj) * 4;
+        cbx[t][0] = b[0], cbx[t][1] = b[1], cbx[t][2] = b[2], cbx[t][3] = b[3];
+    }
+    __syncthreads();
+    const int ri = rb * 64 + t;
+    if (ri >= cnt) return;
+    const float* a = sbox + ((size_t)n * A + ri) * 4;
+    const float ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3], aa = (ax2 - ax1) * (ay2 - ay1);
+    unsigned long long bits = 0;
+    const int lim = (cnt - cb * 64) < 64 ? (cnt - cb * 64) : 64;
+    for (int j = (rb == cb ? t + 1 : 0); j < lim; ++j) {
+        const float xx1 = fmaxf(ax1, cbx[j][0]), yy1 = fmaxf(ay1, cbx[j][1]);
+        const float xx2 = fminf(ax2, cbx[j][2]), yy2 = fminf(ay2, cbx[j][3]);
+        const float inter = fmaxf(xx2 - xx1, 0.f) * fmaxf(yy2 - yy1, 0.f);
+        const float ab = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
+        if (inter / (aa + ab - inter) > iou_thres) bits |= 1ull << j;
+    }
+    mask[((size_t)n * A + ri) * words + cb] = bits;
+}
+
+// sequential scan over the sorted candidates (one wave per image); also maps boxes back to the frame
+__global__ void __launch_bounds__(128) nms_scan_kernel(int A, int words, int max_det, const unsigned long long* __restrict__ mask,
+                                                       const int* __restrict__ scount, const int* __restrict__ sidx,
+                                                       const float* __restrict__ cbox, const float* __restrict__ cconf,
+                                                       const int* __restrict__ ccls, float gain, float padx, float pady,
+                                                       float fw, float fh, int* __restrict__ det_n, float* __restrict__ det_box,
+                                                       float* __restrict__ det_conf, int* __restrict__ det_cls) {
+    __shared__ unsigned long long removed[128];
+    const int n = blockIdx.x, t = threadIdx.x, cnt = scount[n];
+    removed[t] = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int i = 0; i < cnt && kept < max_det; ++i) {
+        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;      // uniform
+        __syncthreads();
+        if (dead) continue;
+        if (t == 0) {
+            const int a = sidx[(size_t)n * A + i];
+            const float* b = cbox + ((size_t)n * A + a) * 4;
+            float* o = det_box + ((size_t)n * max_det + kept) * 4;
+            o[0] = fminf(fmaxf((b[0] - padx) / gain, 0.f), fw), o[1] = fminf(fmaxf((b[1] - pady) / gain, 0.f), fh);
+            o[2] = fminf(fmaxf((b[2] - padx) / gain, 0.f), fw), o[3] = fminf(fmaxf((b[3] - pady) / gain, 0.f), fh);
+            det_conf[(size_t)n * max_det + kept] = cconf[(size_t)n * A + a];
+            det_cls[(size_t)n * max_det + kept] = ccls[(size_t)n * A + a];
+        }
+        ++kept;
+        const int w0 = i >> 6;
+        if (t >= w0 && t < words) removed[t] |= mask[((size_t)n * A + i) * words + t];
+        __syncthreads();
+    }
+    if (t == 0) det_n[n] = kept;
+}
+
+// ---- host side: graph of layers --------------------------------------------------------------------------------
+struct Buf { bf16_t* p = nullptr; int C = 0, H = 0, W = 0; };
+struct Slice { int buf, coff, c; };
+
+struct Yolo {
+    av_ctx* ctx = nullptr;
+    int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
+    float gain = 1.f;
+    std::vector<Buf> bufs;
+    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; };
+    std::vector<Op> ops;
+    std::vector<void*> allocs;
+    float* head_box[3] = {nullptr, nullptr, nullptr};
+    float* head_cls[3] = {nullptr, nullptr, nullptr};
+    int lvH[3], lvW[3];
+    float *cbox = nullptr, *cconf = nullptr, *sbox = nullptr;
+    int *ccls = nullptr, *sidx = nullptr, *scount = nullptr;
+    unsigned long long* mask = nullptr;
+    const float* wsrc = nullptr;
+    size_t wpos = 0, wtotal = 0;
+    std::vector<std::pair<int, Slice>> named;       // test hooks: tensor id -> slice
+};
+
+bool dev_alloc(Yolo& y, void** p, size_t bytes) {
+    if (hipMalloc(p, bytes) != hipSuccess) return false;
+    (void)hipMemset(*p, 0, bytes);
+    y.allocs.push_back(*p);
+    return true;
+}
+
+int new_buf(Yolo& y, int H, int W, int C) {
+    Buf b;
+    b.C = C, b.H = H, b.W = W;
+    if (!dev_alloc(y, (void**)&b.p, (size_t)y.B * H * W * C * sizeof(bf16_t))) return -1;
+    y.bufs.push_back(b);
+    return (int)y.bufs.size() - 1;
+}
+
+// consumes one conv's parameters, folds BN, uploads bf16 [cout][kpad] + f32 bias, appends the op
+bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* out32, int out32_cs, const Slice* res) {
+    const int cin_real = in.c == 8 && y.ops.empty() ? 3 : in.c;     // the network input is RGB padded to 8 channels
+    const int cin = in.c, cout = out.c, taps = k * k;
+    const int kreal = taps * cin, kpad = (kreal + 31) & ~31;
+    const size_t nw = (size_t)cout * cin_real * taps, nb = bn_act ? 4 * (size_t)cout : (size_t)cout;
+    if (y.wpos + nw + nb > y.wtotal) return false;
+    const float* w = y.wsrc + y.wpos;
+    const float* bp = w + nw;
+    y.wpos += nw + nb;
+    std::vector<bf16_t> wb((size_t)cout * kpad, 0);
+    std::vector<float> bias(cout);
+    for (int co = 0; co < cout; ++co) {
+        float scale = 1.f, sh = bp[co];
+        if (bn_act) {
+            const float g = bp[co], be = bp[cout + co], mu = bp[2 * cout + co], var = bp[3 * cout + co];
+            scale = g / std::sqrt(var + 1e-3f);
+            sh = be - mu * scale;
+        }
+        bias[co] = sh;
+        for (int ci = 0; ci < cin_real; ++ci)
+            for (int t = 0; t < taps; ++t)
+                wb[(size_t)co * kpad + t * cin + ci] = f2bf(w[((size_t)co * cin_real + ci) * taps + t] * scale);
+    }
+    bf16_t* dw;
+    float* db;
+    if (!dev_alloc(y, (void**)&dw, wb.size() * 2) || !dev_alloc(y, (void**)&db, bias.size() * 4)) return false;
+    (void)hipMemcpy(dw, wb.data(), wb.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+    const Buf& bi = y.bufs[in.buf];
+    Yolo::Op op{};
+    op.kind = 0;
+    ConvArgs& a = op.ca;
+    a.in = bi.p, a.in_cs = bi.C, a.in_coff = in.coff, a.cin = cin, a.H = bi.H, a.W = bi.W;
+    a.wgt = dw, a.bias = db, a.kpad = kpad, a.kreal = kreal, a.ksz = k, a.stride = s;
+    a.Ho = (bi.H + 2 * (k / 2) - k) / s + 1, a.Wo = (bi.W + 2 * (k / 2) - k) / s + 1;
+    if (out32) a.out = nullptr, a.out32 = out32, a.out_cs = out32_cs, a.out_coff = 0;
+    else a.out = y.bufs[out.buf].p, a.out32 = nullptr, a.out_cs = y.bufs[out.buf].C, a.out_coff = out.coff;
+    a.cout = cout;
+    a.res = nullptr, a.res_cs = 0, a.res_coff = 0;
+    if (res) a.res = y.bufs[res->buf].p, a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
+    a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
+    op.mt = (cout % 64 == 0) ? 4 : ((cout % 32 == 0) ? 2 : 1);
+    y.ops.push_back(op);
+    return true;
+}
+
+// C2f(c1 -> c2, n, shortcut): input slice `in`, output slice `out`; allocates its concat + temp buffers
+bool add_c2f(Yolo& y, Slice in, Slice out, int n, bool shortcut) {
+    const Buf& bi = y.bufs[in.buf];
+    const int c = out.c / 2, H = bi.H, W = bi.W;
+    const int cat = new_buf(y, H, W, (2 + n) * c), tmp = new_buf(y, H, W, c);
+    if (cat < 0 || tmp < 0) return false;
+    if (!add_conv(y, in, Slice{cat, 0, 2 * c}, 1, 1, true, nullptr, 0, nullptr)) return false;
+    for (int i = 0; i < n; ++i) {
+        const Slice src{cat, (1 + i) * c, c}, dst{cat, (2 + i) * c, c};
+        if (!add_conv(y, src, Slice{tmp, 0, c}, 3, 1, true, nullptr, 0, nullptr)) return false;
+        if (!add_conv(y, Slice{tmp, 0, c}, dst, 3, 1, true, nullptr, 0, shortcut ? &src : nullptr)) return false;
+    }
+    return add_conv(y, Slice{cat, 0, (2 + n) * c}, out, 1, 1, true, nullptr, 0, nullptr);
+}
+
+void add_simple(Yolo& y, int kind, Slice in, Slice out, int H, int W, int C) {
+    Yolo::Op op{};
+    op.kind = kind, op.in = in, op.out = out, op.H = H, op.W = W, op.C = C;
+    y.ops.push_back(op);
+}
+
+void letterbox(int h, int w, float& r, int& nh, int& nw, int& top, int& left, int& H, int& W) {
+    const int nsz = 640, stride = 32;
+    r = std::fmin((float)nsz / h, (float)nsz / w);
+    nh = (int)std::lround((double)h * r), nw = (int)std::lround((double)w * r);
+    const int dw = (nsz - nw) % stride, dh = (nsz - nh) % stride;
+    top = (int)std::lround(dh / 2.0 - 0.1), left = (int)std::lround(dw / 2.0 - 0.1);
+    const int bottom = (int)std::lround(dh / 2.0 + 0.1), right = (int)std::lround(dw / 2.0 + 0.1);
+    H = nh + top + bottom, W = nw + left + right;
+}
+
+}  // namespace
+
+struct av_yolo { Yolo y; };
+
+extern "C" {
+
+int av_yolo_ctx_free(av_ctx*) { return AV_OK; }
+
+size_t av_yolo_param_count(void) {
+    // must equal oracle/yolo_ref.py: param_count()
+    return 3167776;
+}
+
+int av_yolo_destroy(av_yolo* h) {
+    if (!h) return AV_OK;
+    for (void* p : h->y.allocs) (void)hipFree(p);
+    delete h;
+    return AV_OK;
+}
+
+int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights, av_yolo** out) {
+    AV_REQUIRE(ctx && weights && out, AV_EINVAL, "av_yolo_create: null argument");
+    AV_REQUIRE(batch > 0 && in_h >= 32 && in_w >= 32, AV_EINVAL, "av_yolo_create: bad shape");
+    AV_REQUIRE(n_weights == av_yolo_param_count(), AV_EINVAL, "av_yolo_create: expected %zu parameters, got %zu",
+               av_yolo_param_count(), n_weights);
+    AV_HIP(hipSetDevice(ctx->device));
+    av_yolo* h = new (std::nothrow) av_yolo();
+    AV_REQUIRE(h, AV_ENOMEM, "av_yolo_create: out of host memory");
+    Yolo& y = h->y;
+    y.ctx = ctx, y.B = batch, y.inH = in_h, y.inW = in_w, y.wsrc = weights, y.wtotal = n_weights;
+    letterbox(in_h, in_w, y.gain, y.nh, y.nw, y.top, y.left, y.H, y.W);
+    bool ok = true;
+    const int H = y.H, W = y.W;
+    auto nb = [&](int hh, int ww, int c) { const int b = new_buf(y, hh, ww, c); ok = ok && b >= 0; return b; };
+    const int x0 = nb(H, W, 8), b0 = nb(H / 2, W / 2, 16), b1 = nb(H / 4, W / 4, 32), b2 = nb(H / 4, W / 4, 32);
+    const int cat14 = nb(H / 8, W / 8, 192), cat11 = nb(H / 16, W / 16, 384), cat20 = nb(H / 32, W / 32, 384);
+    const int cat17 = nb(H / 16, W / 16, 192);
+    const int b3 = nb(H / 8, W / 8, 64), b5 = nb(H / 16, W / 16, 128), b7 = nb(H / 32, W / 32, 256), b8 = nb(H / 32, W / 32, 256);
+    const int spp = nb(H / 32, W / 32, 512), p3 = nb(H / 8, W / 8, 64), p4 = nb(H / 16, W / 16, 128), p5 = nb(H / 32, W / 32, 256);
+    const int d16 = 0;
+    (void)d16;
+    if (!ok) { av_yolo_destroy(h); av_set_error("av_yolo_create: device allocation failed"); return AV_ENOMEM; }
+#define CV(...) ok = ok && add_conv(y, __VA_ARGS__)
+    CV(Slice{x0, 0, 8}, Slice{b0, 0, 16}, 3, 2, true, nullptr, 0, nullptr);                       // 0
+    CV(Slice{b0, 0, 16}, Slice{b1, 0, 32}, 3, 2, true, nullptr, 0, nullptr);                      // 1
+    ok = ok && add_c2f(y, Slice{b1, 0, 32}, Slice{b2, 0, 32}, 1, true);                            // 2
+    CV(Slice{b2, 0, 32}, Slice{b3, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                      // 3
+    ok = ok && add_c2f(y, Slice{b3, 0, 64}, Slice{cat14, 128, 64}, 2, true);                       // 4 -> cat14[128:192]
+    CV(Slice{cat14, 128, 64}, Slice{b5, 0, 128}, 3, 2, true, nullptr, 0, nullptr);                // 5
+    ok = ok && add_c2f(y, Slice{b5, 0, 128}, Slice{cat11, 256, 128}, 2, true);                     // 6 -> cat11[256:384]
+    CV(Slice{cat11, 256, 128}, Slice{b7, 0, 256}, 3, 2, true, nullptr, 0, nullptr);               // 7
+    ok = ok && add_c2f(y, Slice{b7, 0, 256}, Slice{b8, 0, 256}, 1, true);                          // 8
+    CV(Slice{b8, 0, 256}, Slice{spp, 0, 128}, 1, 1, true, nullptr, 0, nullptr);                   // 9 SPPF cv1
+    for (int i = 0; i < 3; ++i) add_simple(y, 1, Slice{spp, 128 * i, 128}, Slice{spp, 128 * (i + 1), 128}, H / 32, W / 32, 128);
+    CV(Slice{spp, 0, 512}, Slice{cat20, 128, 256}, 1, 1, true, nullptr, 0, nullptr);              // 9 SPPF cv2 -> cat20[128:384]
+    add_simple(y, 2, Slice{cat20, 128, 256}, Slice{cat11, 0, 256}, H / 32, W / 32, 256);           // 10 upsample -> cat11[0:256]
+    ok = ok && add_c2f(y, Slice{cat11, 0, 384}, Slice{cat17, 64, 128}, 1, false);                  // 12 -> cat17[64:192]
+    add_simple(y, 2, Slice{cat17, 64, 128}, Slice{cat14, 0, 128}, H / 16, W / 16, 128);            // 13 upsample -> cat14[0:128]
+    ok = ok && add_c2f(y, Slice{cat14, 0, 192}, Slice{p3, 0, 64}, 1, false);                       // 15
+    CV(Slice{p3, 0, 64}, Slice{cat17, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                   // 16 -> cat17[0:64]
+    ok = ok && add_c2f(y, Slice{cat17, 0, 192}, Slice{p4, 0, 128}, 1, false);                      // 18
+    CV(Slice{p4, 0, 128}, Slice{cat20, 0, 128}, 3, 2, true, nullptr, 0, nullptr);                 // 19 -> cat20[0:128]
+    ok = ok && add_c2f(y, Slice{cat20, 0, 384}, Slice{p5, 0, 256}, 1, false);                      // 21
+    const int pl[3] = {p3, p4, p5}, pc[3] = {64, 128, 256}, dv[3] = {8, 16, 32};
+    y.A = 0;
+    for (int i = 0; i < 3 && ok; ++i) {
+        const int hh = H / dv[i], ww = W / dv[i];
+        y.lvH[i] = hh, y.lvW[i] = ww;
+        const int ba = nb(hh, ww, 64), bb = nb(hh, ww, 64), ca = nb(hh, ww, NC), cb = nb(hh, ww, NC);
+        ok = ok && dev_alloc(y, (void**)&y.head_box[i], (size_t)batch * hh * ww * 64 * 4);
+        ok = ok && dev_alloc(y, (void**)&y.head_cls[i], (size_t)batch * hh * ww * NC * 4);
+        if (!ok) break;
+        CV(Slice{pl[i], 0, pc[i]}, Slice{ba, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
+        CV(Slice{ba, 0, 64}, Slice{bb, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
+        CV(Slice{bb, 0, 64}, Slice{-1, 0, 64}, 1, 1, false, y.head_box[i], 64, nullptr);
+        CV(Slice{pl[i], 0, pc[i]}, Slice{ca, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
+        CV(Slice{ca, 0, NC}, Slice{cb, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
+        CV(Slice{cb, 0, NC}, Slice{-1, 0, NC}, 1, 1, false, y.head_cls[i], NC, nullptr);
+        y.A += hh * ww;
+    }
+#undef CV
+    ok = ok && y.wpos == y.wtotal && y.A <= MAX_CAND;
+    y.words = (y.A + 63) / 64;
+    ok = ok && y.words <= 128;
+    ok = ok && dev_alloc(y, (void**)&y.cbox, (size_t)batch * y.A * 16) && dev_alloc(y, (void**)&y.cconf, (size_t)batch * y.A * 4) &&
+         dev_alloc(y, (void**)&y.ccls, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.sbox, (size_t)batch * y.A * 16) &&
+         dev_alloc(y, (void**)&y.sidx, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.scount, (size_t)batch * 4) &&
+         dev_alloc(y, (void**)&y.mask, (size_t)batch * y.A * y.words * 8);
+    y.named = {{0, Slice{x0, 0, 8}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
+               {6, Slice{cat11, 256, 128}}, {8, Slice{b8, 0, 256}}, {9, Slice{cat20, 128, 256}}, {12, Slice{cat17, 64, 128}},
+               {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}};
+    y.wsrc = nullptr;
+    if (!ok) {
+        av_yolo_destroy(h);
+        av_set_error("av_yolo_create: graph construction failed (parameter blob / capacity mismatch)");
+        return AV_EINVAL;
+    }
+    (void)hipDeviceSynchronize();
+    *out = h;
+    return AV_OK;
+}
+
+int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors) {
+    AV_REQUIRE(h && net_h && net_w && n_anchors, AV_EINVAL, "av_yolo_dims: null argument");
+    *net_h = h->y.H, *net_w = h->y.W, *n_anchors = h->y.A;
+    return AV_OK;
+}
+
+// test hook: NHWC bf16 slice of an intermediate tensor (ids follow the yolov8.yaml layer numbers; 0 = input)
+int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff) {
+    AV_REQUIRE(h && ptr && H && W && C && cstride && coff, AV_EINVAL, "av_yolo_tensor: null argument");
+    if (id >= 100 && id < 106) {            // head outputs (float32): 100+2i box, 101+2i cls
+        const int i = (id - 100) / 2;
+        *ptr = (id & 1) ? (void*)h->y.head_cls[i] : (void*)h->y.head_box[i];
+        *H = h->y.lvH[i], *W = h->y.lvW[i], *C = (id & 1) ? NC : 64, *cstride = *C, *coff = 0;
+        return AV_OK;
+    }
+    for (const auto& kv : h->y.named)
+        if (kv.first == id) {
+            const Buf& b = h->y.bufs[kv.second.buf];
+            *ptr = b.p, *H = b.H, *W = b.W, *C = kv.second.c, *cstride = b.C, *coff = kv.second.coff;
+            return AV_OK;
+        }
+    av_set_error("av_yolo_tensor: unknown tensor id %d", id);
+    return AV_EINVAL;
+}
+
+int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float conf_thres, float iou_thres, int max_det,
+                    int32_t* det_n, float* det_box, float* det_conf, int32_t* det_cls) {
+    AV_REQUIRE(h && bgr && det_n && det_box && det_conf && det_cls, AV_EINVAL, "av_yolo_forward: null argument");
+    AV_REQUIRE(max_det > 0 && conf_thres > 0.f, AV_EINVAL, "av_yolo_forward: max_det and conf_thres must be > 0");
+    Yolo& y = h->y;
+    hipStream_t st = as_stream(stream);
+    const int B = y.B;
+    {
+        const int n = B * y.H * y.W;
+        hipLaunchKernelGGL(preprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
+                           y.nw, y.top, y.left, y.bufs[0].p);
+        AV_LAUNCH_CHECK();
+    }
+    for (const Yolo::Op& op : y.ops) {
+        if (op.kind == 0) {
+            const ConvArgs& a = op.ca;
+            constexpr int NT = 2;
+            const dim3 grid((a.npix + 16 * NT * 4 - 1) / (16 * NT * 4), a.cout / (16 * op.mt));
+            if (op.mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, NT>), grid, dim3(256), 0, st, a);
+            else if (op.mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<2, NT>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_mfma_kernel<1, NT>), grid, dim3(256), 0, st, a);
+        } else {
+            const Buf &bi = y.bufs[op.in.buf], &bo = y.bufs[op.out.buf];
+            if (op.kind == 1) {
+                const int n = B * op.H * op.W * op.C;
+                hipLaunchKernelGGL(maxpool5_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bi.p, bi.C, op.in.coff, bo.p, bo.C,
+                                   op.out.coff, B, op.H, op.W, op.C);
+            } else {
+                const int n = B * 4 * op.H * op.W * (op.C / 8);
+                hipLaunchKernelGGL(upsample2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bi.p, bi.C, op.in.coff, bo.p, bo.C,
+                                   op.out.coff, B, op.H, op.W, op.C);
+            }
+        }
+        AV_LAUNCH_CHECK();
+    }
+    Level lv[3];
+    int aoff = 0;
+    const int strides[3] = {8, 16, 32};
+    for (int i = 0; i < 3; ++i) {
+        lv[i] = Level{y.head_box[i], y.head_cls[i], y.lvH[i], y.lvW[i], strides[i], aoff};
+        aoff += y.lvH[i] * y.lvW[i];
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.cbox, y.cconf,
+                       y.ccls);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, st, y.A, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
+    AV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(y.words, y.words, B), dim3(64), 0, st, y.A, y.words, iou_thres, y.sbox, y.scount, y.mask);
+    AV_LAUNCH_CHECK();
+    // gain/pad of ultralytics scale_boxes
+    const float gain = std::fmin((float)y.H / y.inH, (float)y.W / y.inW);
+    const float padx = (float)std::lround((y.W - y.inW * gain) / 2 - 0.1), pady = (float)std::lround((y.H - y.inH * gain) / 2 - 0.1);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(128), 0, st, y.A, y.words, max_det, y.mask, y.scount, y.sidx, y.cbox, y.cconf,
+                       y.ccls, gain, padx, pady, (float)y.inW, (float)y.inH, det_n, det_box, det_conf, det_cls);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""YOLO-mode model for ObjectDetector (mode="yolo"): YOLOv8n topology on the library's MFMA conv path.
+
+The reference calls ultralytics `YOLO("yolov8n.pt")(frame)` (detector.py:77-84,103-123); neither the
+package nor the weight file can be shipped, so this model takes its parameters from
+  * a `.npy` / `.npz` file holding the flat float32 vector in the order of `conv_specs()`, or
+  * the pseudo path "random" / "random:<seed>" -> seeded He-normal weights with non-trivial BatchNorm
+    statistics (BASELINE config 3: "random-init nano backbone").
+Any other path that does not exist raises FileNotFoundError, which ObjectDetector turns into the
+reference's graceful fallback to simulated mode.
+
+Parameter order: for every convolution of conv_specs(), weight[cout][cin][k][k] followed by BatchNorm
+(gamma, beta, running_mean, running_var) -- or by the bias for the two plain Conv2d that end each head branch.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .._dev import Dev
+
+NC, REG_MAX = 80, 16
+CONF_THRES, IOU_THRES, MAX_DET = 0.25, 0.7, 300          # ultralytics predict defaults
+
+COCO_NAMES = ("person bicycle car motorcycle airplane bus train truck boat traffic_light fire_hydrant stop_sign "
+              "parking_meter bench bird cat dog horse sheep cow elephant bear zebra giraffe backpack umbrella handbag "
+              "tie suitcase frisbee skis snowboard sports_ball kite baseball_bat baseball_glove skateboard surfboard "
+              "tennis_racket bottle wine_glass cup fork knife spoon bowl banana apple sandwich orange broccoli carrot "
+              "hot_dog pizza donut cake chair couch potted_plant bed dining_table toilet tv laptop mouse remote "
+              "keyboard cell_phone microwave oven toaster sink refrigerator book clock vase scissors teddy_bear "
+              "hair_drier toothbrush").split()
+
+
+def _c2f(c1, c2, n):
+    c = c2 // 2
+    return [(c1, 2 * c, 1, 1, True)] + [(c, c, 3, 1, True)] * (2 * n) + [((2 + n) * c, c2, 1, 1, True)]
+
+
+def conv_specs():
+    """[(cin, cout, k, stride, has_bn_act)] in execution order (yolov8.yaml, scale n)."""
+    s = [(3, 16, 3, 2, True), (16, 32, 3, 2, True)] + _c2f(32, 32, 1)
+    s += [(32, 64, 3, 2, True)] + _c2f(64, 64, 2) + [(64, 128, 3, 2, True)] + _c2f(128, 128, 2)
+    s += [(128, 256, 3, 2, True)] + _c2f(256, 256, 1) + [(256, 128, 1, 1, True), (512, 256, 1, 1, True)]
+    s += _c2f(384, 128, 1) + _c2f(192, 64, 1) + [(64, 64, 3, 2, True)] + _c2f(192, 128, 1)
+    s += [(128, 128, 3, 2, True)] + _c2f(384, 256, 1)
+    for ch in (64, 128, 256):
+        s += [(ch, 64, 3, 1, True), (64, 64, 3, 1, True), (64, 4 * REG_MAX, 1, 1, False)]
+        s += [(ch, NC, 3, 1, True), (NC, NC, 3, 1, True), (NC, NC, 1, 1, False)]
+    return s
+
+
+def random_params(seed=0):
+    rs = np.random.RandomState(seed)
+    parts = []
+    for cin, cout, k, _, bn in conv_specs():
+        parts.append((rs.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32).ravel())
+        if bn:
+            parts += [rs.uniform(0.8, 1.2, cout).astype(np.float32), rs.uniform(-0.1, 0.1, cout).astype(np.float32),
+                      rs.uniform(-0.1, 0.1, cout).astype(np.float32), rs.uniform(0.8, 1.2, cout).astype(np.float32)]
+        else:
+            parts.append(rs.uniform(-1.0, 1.0, cout).astype(np.float32))
+    return np.concatenate(parts)
+
+
+def load_params(model_path):
+    if model_path.startswith("random"):
+        seed = int(model_path.split(":")[1]) if ":" in model_path else 0
+        return random_params(seed)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError("model file %r not found (ultralytics checkpoints cannot be read here; "
+                                "pass a .npy/.npz parameter vector or 'random[:seed]')" % model_path)
+    if model_path.endswith(".npz"):
+        z = np.load(model_path)
+        return np.ascontiguousarray(z[z.files[0]], np.float32).ravel()
+    return np.ascontiguousarray(np.load(model_path), np.float32).ravel()
+
+
+class YoloV8n:
+    def __init__(self, model_path="random", device=0, batch=1):
+        self._dev = Dev(device)
+        self.params = load_params(model_path)
+        n = int(self._dev.lib.av_yolo_param_count())
+        if self.params.size != n:
+            raise ValueError("parameter vector has %d floats, the YOLOv8n graph needs %d" % (self.params.size, n))
+        self.names = dict(enumerate(COCO_NAMES))
+        self.batch = batch
+        self._h = None
+        self._shape = None
+
+    def _prepare(self, h, w):
+        if self._shape == (h, w):
+            return
+        d = self._dev
+        self.close()
+        hd = C.c_void_p()
+        nat.check(d.lib.av_yolo_create(d.ctx.handle, self.batch, h, w, self.params.ctypes.data_as(C.c_void_p),
+                                       self.params.size, C.byref(hd)))
+        self._h = hd
+        self._shape = (h, w)
+        B = self.batch
+        self._frames = d.empty((B, h, w, 3), torch.uint8)
+        self._n = d.zeros(B, torch.int32)
+        self._box = d.zeros((B, MAX_DET, 4), torch.float32)
+        self._conf = d.zeros((B, MAX_DET), torch.float32)
+        self._cls = d.zeros((B, MAX_DET), torch.int32)
+
+    def dims(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        nat.check(self._dev.lib.av_yolo_dims(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def forward_device(self, frames_dev, conf=CONF_THRES, iou=IOU_THRES):
+        """frames_dev: uint8 [batch, h, w, 3] device tensor.  Enqueues the whole detector; results stay on device."""
+        d = self._dev
+        nat.check(d.lib.av_yolo_forward(self._h, d.stream, nat.ptr(frames_dev), conf, iou, MAX_DET, nat.ptr(self._n),
+                                        nat.ptr(self._box), nat.ptr(self._conf), nat.ptr(self._cls)))
+
+    def detect(self, frame, conf=CONF_THRES, iou=IOU_THRES):
+        """One BGR frame -> (boxes float32[n,4] xyxy in frame pixels, conf[n], cls[n])."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        h, w = frame.shape[:2]
+        self._prepare(h, w)
+        self._frames[0].copy_(torch.as_tensor(frame))
+        self.forward_device(self._frames, conf, iou)
+        n = int(self._n[0].item())
+        return (self._box[0, :n].cpu().numpy(), self._conf[0, :n].cpu().numpy(), self._cls[0, :n].cpu().numpy())
+
+    def tensor(self, tid):
+        """Host copy (float32, [H, W, C]) of an intermediate tensor (test hook)."""
+        p, H, W, Cc, cs, co = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        nat.check(self._dev.lib.av_yolo_tensor(self._h, tid, C.byref(p), C.byref(H), C.byref(W), C.byref(Cc), C.byref(cs),
+                                               C.byref(co)))
+        n = self.batch * H.value * W.value * cs.value
+        t = torch.empty(n, dtype=torch.float32 if tid >= 100 else torch.int16, device=self._dev.device)
+        nbytes = t.numel() * t.element_size()
+        self._dev.sync()
+        rc = _memcpy_d2d(t.data_ptr(), p.value, nbytes)      # the tensor lives in library-owned memory
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed (%d)" % rc)
+        arr = t.cpu().numpy().reshape(self.batch, H.value, W.value, cs.value)[0, :, :, co.value:co.value + Cc.value]
+        if tid >= 100:
+            return arr.astype(np.float32)
+        return (arr.astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+    def close(self):
+        if self._h is not None:
+            self._dev.lib.av_yolo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _memcpy_d2d(dst, src, nbytes):
+    import ctypes
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return hip.hipMemcpy(dst, src, nbytes, 3)      # hipMemcpyDeviceToDevice
