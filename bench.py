@@ -79,7 +79,7 @@ def main():
     from oracle.harness_ref import ego_motion
 
     S = a.streams or (1 if a.workload == "config2" else 64)
-    W = a.window or (2048 if a.workload == "config2" else 256)
+    W = a.window or (32768 if a.workload == "config2" else 256)
     loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True)
     L = nat.lib()
     g0 = rank * S                                      # global stream ids of this rank
@@ -153,11 +153,13 @@ def main():
 
     if rank == 0:
         frames = S * W * a.steps * world
+        # HBM bytes per launch from the PMC counters (WRITE_SIZE + corrected FETCH_SIZE), collected with
+        # rocprofv3 in separate passes and committed under profiles/ (per start state, scaled to this launch)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "planner_pmc_%s.json" % a.workload)
+        pmc = os.path.join(ROOT, "profiles", "planner_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = int(json.load(open(pmc))["hbm_bytes_per_state"] * S * W)
             except Exception:
                 traffic = None
         out = {
@@ -169,7 +171,7 @@ def main():
                                    "tracker + 6-state KF + 21-candidate planner" % (a.workload, S, W),
                        "streams_per_gpu": S, "window": W, "graph": bool(a.graph),
                        "allgather_track_tables": bool(xchg is not None), "parallelism": "stream-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "planner_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "planner_wave_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": plan_bytes, "avg_launch_ms": round(plan_ms, 5)},
         }
