@@ -432,29 +432,260 @@ __global__ void __launch_bounds__(256) sobel_nms_fast(const uint8_t* __restrict_
     *reinterpret_cast<uint4*>(map + ((size_t)s * h + y) * w + x0 + c0) = *reinterpret_cast<const uint4*>(o);
 }
 
+// ===== streaming kernels (w % 4 == 0): no LDS tiles; a lane owns 4 adjacent pixels of a column strip and
+// slides down the rows, exchanging row neighbours with DPP.  A wave covers 64 chunks = 256 columns of which
+// lanes 0 and 63 are halo (strip pitch 248 columns); image borders are resolved by permuting the edge lane's
+// own pixels (reflect-101 for the blur, replicate for Sobel).
+
+__device__ __forceinline__ unsigned dpp_prev_u32(unsigned v) {      // value of lane-1 (0 for lane 0)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned dpp_next_u32(unsigned v) {      // value of lane+1 (0 for lane 63)
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+}
+
+constexpr int SW = 248;                 // output columns per wave strip (62 lanes x 4)
+constexpr int SROWS = 48;               // output rows per wave
+
+__global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __restrict__ bgr, int h, int w,
+                                                             uint8_t* __restrict__ blur, unsigned* __restrict__ hist) {
+    __shared__ unsigned lh[16 * 256];
+    const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 16 * 256; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int strip = blockIdx.x, x0 = strip * SW - 4;          // column of lane 0's first pixel (halo lane)
+    const int yb = (blockIdx.y * 4 + wid) * SROWS;              // first output row of this wave
+    const int x = x0 + 4 * lane;                                // this lane's columns x .. x+3
+    const bool xin = x >= 0 && x + 4 <= w;                      // chunk fully inside the image (w % 4 == 0)
+    const bool out_lane = lane >= 1 && lane <= 62 && xin;
+    const uint8_t* img = bgr + (size_t)s * h * w * 3;
+    uint8_t* dst = blur + (size_t)s * h * w;
+    if (yb < h) {
+        // horizontal pass results of the last five rows, two u16 pairs per row (pixels 0,1 | 2,3)
+        unsigned ra[5], rb[5];
+        const int y_end = (yb + SROWS < h ? yb + SROWS : h);
+        for (int yy = yb - 2; yy < y_end + 2; ++yy) {
+            const int ys = reflect101(yy, h);
+            unsigned g = 0;                                     // 4 gray bytes, pixel 0 in the low byte
+            if (xin) {
+                const unsigned* p = reinterpret_cast<const unsigned*>(img + ((size_t)ys * w + x) * 3);
+                const unsigned a = p[0], b = p[1], c = p[2];    // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                const unsigned g0 = (1868u * (a & 255u) + 9617u * ((a >> 8) & 255u) + 4899u * ((a >> 16) & 255u) + 8192u) >> 14;
+                const unsigned g1 = (1868u * (a >> 24) + 9617u * (b & 255u) + 4899u * ((b >> 8) & 255u) + 8192u) >> 14;
+                const unsigned g2 = (1868u * ((b >> 16) & 255u) + 9617u * (b >> 24) + 4899u * (c & 255u) + 8192u) >> 14;
+                const unsigned g3 = (1868u * ((c >> 8) & 255u) + 9617u * ((c >> 16) & 255u) + 4899u * (c >> 24) + 8192u) >> 14;
+                g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+            }
+            unsigned gp = dpp_prev_u32(g), gn = dpp_next_u32(g);
+            // reflect-101 at the image borders: columns -2,-1 are columns 2,1; columns w,w+1 are w-2,w-3
+            if (x == 0) gp = ((g >> 16) & 255u) << 16 | ((g >> 8) & 255u) << 24;          // [.,.,g2,g1]
+            if (x + 4 == w) gn = ((g >> 16) & 255u) | (((g >> 8) & 255u) << 8);            // [g2,g1,.,.]
+            const unsigned m2 = gp >> 16 & 255u, m1 = gp >> 24, p0 = g & 255u, p1 = (g >> 8) & 255u, p2 = (g >> 16) & 255u,
+                           p3 = g >> 24, n0 = gn & 255u, n1 = (gn >> 8) & 255u;
+            const unsigned h0 = m2 + 4 * m1 + 6 * p0 + 4 * p1 + p2, h1 = m1 + 4 * p0 + 6 * p1 + 4 * p2 + p3;
+            const unsigned h2 = p0 + 4 * p1 + 6 * p2 + 4 * p3 + n0, h3 = p1 + 4 * p2 + 6 * p3 + 4 * n0 + n1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ra[q] = ra[q + 1], rb[q] = rb[q + 1];
+            ra[4] = h0 | (h1 << 16), rb[4] = h2 | (h3 << 16);
+            const int yo = yy - 2;                              // output row completed by this input row
+            if (yo >= yb && out_lane) {
+                // vertical pass on packed u16 pairs: max 16*4080 + 128 < 65536, no carry between the halves
+                const unsigned va = ra[0] + ra[4] + 4u * (ra[1] + ra[3]) + 6u * ra[2] + 0x00800080u;
+                const unsigned vb = rb[0] + rb[4] + 4u * (rb[1] + rb[3]) + 6u * rb[2] + 0x00800080u;
+                const unsigned o0 = (va >> 8) & 255u, o1 = va >> 24, o2 = (vb >> 8) & 255u, o3 = vb >> 24;
+                *reinterpret_cast<unsigned*>(dst + (size_t)yo * w + x) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+                // histogram with run merging
+                unsigned* hl = lh + (lane & 15) * 256;
+                if (o0 == o1 && o1 == o2 && o2 == o3) atomicAdd(&hl[o0], 4u);
+                else {
+                    atomicAdd(&hl[o0], 1u), atomicAdd(&hl[o1], 1u), atomicAdd(&hl[o2], 1u), atomicAdd(&hl[o3], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += lh[q * 256 + tid];
+    if (tot) atomicAdd(&hist[(size_t)s * 256 + tid], tot);
+}
+
+__global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restrict__ blur, int h, int w,
+                                                        const double* __restrict__ thr, uint8_t* __restrict__ map,
+                                                        unsigned* __restrict__ labels) {
+    const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int strip = blockIdx.x, x0 = strip * SW - 4;
+    const int yb = (blockIdx.y * 4 + wid) * SROWS;
+    if (yb >= h) return;
+    const int x = x0 + 4 * lane;
+    const bool xin = x >= 0 && x + 4 <= w;
+    const bool out_lane = lane >= 1 && lane <= 62 && xin;
+    const uint8_t* img = blur + (size_t)s * h * w;
+    int lo = (int)thr[(size_t)s * 4], hi = (int)thr[(size_t)s * 4 + 1];
+    if (lo > hi) { const int q = lo; lo = hi; hi = q; }
+    const int y_end = (yb + SROWS < h ? yb + SROWS : h);
+    // rings: blurred rows (4 u8 + the two horizontal neighbours), magnitude rows (4 u16) and the middle
+    // row's gradients
+    unsigned bc[3], bl[3], br[3];                   // centre bytes, left neighbour byte, right neighbour byte
+    int mg[3][4], gxm[2][4], gym[2][4];
+    unsigned mgl[3], mgr[3];                        // magnitude of column x-1 / x+4 per ring row
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        bc[q] = bl[q] = br[q] = 0, mgl[q] = mgr[q] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mg[q][k] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gxm[q][k] = gym[q][k] = 0;
+    for (int yy = yb - 2; yy < y_end + 2; ++yy) {
+        // ---- stage 1: load blurred row yy (replicate at the borders) ------------------------------------
+        const int ys = clampi(yy, h);
+        unsigned c = 0;
+        if (xin) c = *reinterpret_cast<const unsigned*>(img + (size_t)ys * w + x);
+        unsigned lft = dpp_prev_u32(c) >> 24, rgt = dpp_next_u32(c) & 255u;
+        if (x == 0) lft = c & 255u;
+        if (x + 4 == w) rgt = c >> 24;
+        bc[0] = bc[1], bc[1] = bc[2], bc[2] = c;
+        bl[0] = bl[1], bl[1] = bl[2], bl[2] = lft;
+        br[0] = br[1], br[1] = br[2], br[2] = rgt;
+        // ---- stage 2: Sobel of row yy-1 from blurred rows yy-2, yy-1, yy -----------------------------------
+        const int ym = yy - 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            mgl[q] = mgl[q + 1], mgr[q] = mgr[q + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mg[q][k] = mg[q + 1][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gxm[0][k] = gxm[1][k], gym[0][k] = gym[1][k];
+        {
+            int t[3][6];                                         // columns x-1 .. x+4 of the three rows
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                t[q][0] = (int)bl[q], t[q][5] = (int)br[q];
+                t[q][1] = (int)(bc[q] & 255u), t[q][2] = (int)((bc[q] >> 8) & 255u), t[q][3] = (int)((bc[q] >> 16) & 255u),
+                t[q][4] = (int)(bc[q] >> 24);
+            }
+            const bool row_in = ym >= 0 && ym < h;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int dx = (t[0][k + 2] + 2 * t[1][k + 2] + t[2][k + 2]) - (t[0][k] + 2 * t[1][k] + t[2][k]);
+                const int dy = (t[2][k] + 2 * t[2][k + 1] + t[2][k + 2]) - (t[0][k] + 2 * t[0][k + 1] + t[0][k + 2]);
+                gxm[1][k] = dx, gym[1][k] = dy;
+                mg[2][k] = (row_in && xin) ? abs(dx) + abs(dy) : 0;      // magnitude is 0 outside the image
+            }
+            const unsigned m0 = (unsigned)mg[2][0], m3 = (unsigned)mg[2][3];
+            mgl[2] = dpp_prev_u32(m3);                          // column x-1 (0 outside: halo lanes hold 0)
+            mgr[2] = dpp_next_u32(m0);                          // column x+4
+        }
+        // ---- stage 3: NMS of row yy-2 from magnitude rows yy-3, yy-2, yy-1 ---------------------------------
+        const int yo = yy - 2;
+        if (yo >= yb && yo < y_end && out_lane) {
+            int mm[3][6];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                mm[q][0] = (int)mgl[q], mm[q][5] = (int)mgr[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mm[q][k + 1] = mg[q][k];
+            }
+            unsigned o = 0x01010101u;
+            const int mmax = max(max(mm[1][1], mm[1][2]), max(mm[1][3], mm[1][4]));
+            if (mmax > lo) {
+            o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = mm[1][k + 1];
+                int v = 1;
+                if (m > lo) {
+                    const int xs = gxm[0][k], ysg = gym[0][k];
+                    const int ax = abs(xs), ay = abs(ysg) << 15;
+                    const int tg22x = ax * 13573;
+                    bool is_max;
+                    if (ay < tg22x) is_max = m > mm[1][k] && m >= mm[1][k + 2];
+                    else {
+                        const int tg67x = tg22x + (ax << 16);
+                        if (ay > tg67x) is_max = m > mm[0][k + 1] && m >= mm[2][k + 1];
+                        else {
+                            const bool neg = (xs ^ ysg) < 0;
+                            const int a1 = neg ? mm[0][k + 2] : mm[0][k], a2 = neg ? mm[2][k] : mm[2][k + 2];
+                            is_max = m > a1 && m > a2;
+                        }
+                    }
+                    if (is_max) v = m > hi ? 2 : 0;
+                }
+                o |= (unsigned)v << (8 * k);
+                if (v != 1) {
+                    const unsigned idx = (unsigned)(yo * w + x + k);
+                    labels[(size_t)s * h * w + idx] = v == 2 ? idx : (idx | 0x80000000u);
+                }
+            }
+            }
+            *reinterpret_cast<unsigned*>(map + ((size_t)s * h + yo) * w + x) = o;
+        }
+    }
+}
+
 __device__ __forceinline__ bool all_ones16(const uint4& v) {
     return v.x == 0x01010101u && v.y == 0x01010101u && v.z == 0x01010101u && v.w == 0x01010101u;
 }
 
-// one thread per 16-pixel chunk; chunks without candidates (almost all) cost one 16-byte load
-__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map, int h, int w,
+// Wave-balanced union pass: a wave scans 64 16-pixel chunks (one 16-byte load per lane), appends the
+// candidate pixels it finds to a wave-private LDS list, then the lanes share the list evenly -- edges
+// cluster, so without this one lane would walk all 16 candidates of a chunk (4 unions each) alone.
+__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map, int h, int w, int n_frames,
                                                       unsigned* __restrict__ labels) {
-    const int s = blockIdx.z, cw = w >> 4;
-    const int ci = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (ci >= cw) return;
-    const uint8_t* m = map + (size_t)s * h * w;
-    unsigned* lab = labels + (size_t)s * h * w;
-    const uint4 cur4 = *reinterpret_cast<const uint4*>(m + (size_t)y * w + ci * 16);
-    if (all_ones16(cur4)) return;
-    const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
-    const int xb = ci * 16;
-    for (int k = 0; k < 16; ++k) {
-        if (cur[k] == 1) continue;
-        const int x = xb + k;
-        const unsigned me = (unsigned)(y * w + x);
-        if (x > 0 && (k > 0 ? cur[k - 1] : m[(size_t)y * w + x - 1]) != 1) uf_union(lab, me, me - 1);
-        if (y > 0) {
-            const size_t up = (size_t)(y - 1) * w;
+    __shared__ unsigned list[4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cw = w >> 4;
+    const long long total = (long long)n_frames * h * cw;
+    const long long c0 = ((long long)blockIdx.x * 4 + wid) * 64;
+    if (c0 >= total) return;
+    const long long ci = c0 + lane;
+    unsigned cand = 0;                                   // bit k: pixel k of this lane's chunk is a candidate
+    int s = 0, y = 0, xb = 0;
+    if (ci < total) {
+        s = (int)(ci / ((long long)h * cw));
+        const int r = (int)(ci - (long long)s * h * cw);
+        y = r / cw, xb = (r - y * cw) * 16;
+        const uint4 v = *reinterpret_cast<const uint4*>(map + ((size_t)s * h + y) * w + xb);
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k;
+    }
+    const int mine = __popc(cand);
+    if (__ballot(mine != 0) == 0ull) return;
+    // exclusive prefix of `mine` over the wave
+    int off = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(off, d, 64);
+        if (lane >= d) off += o;
+    }
+    const int n = __shfl(off, 63, 64);
+    off -= mine;
+    unsigned bits = cand;
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        list[wid][off++] = (unsigned)lane << 4 | (unsigned)k;     // (lane of the chunk, pixel in chunk)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    for (int i = lane; i < n; i += 64) {
+        const unsigned e = list[wid][i];
+        const long long cj = c0 + (e >> 4);
+        const int sj = (int)(cj / ((long long)h * cw));
+        const int rj = (int)(cj - (long long)sj * h * cw);
+        const int yj = rj / cw, x = (rj - yj * cw) * 16 + (int)(e & 15u);
+        const uint8_t* m = map + (size_t)sj * h * w;
+        unsigned* lab = labels + (size_t)sj * h * w;
+        const unsigned me = (unsigned)(yj * w + x);
+        if (x > 0 && m[(size_t)yj * w + x - 1] != 1) uf_union(lab, me, me - 1);
+        if (yj > 0) {
+            const size_t up = (size_t)(yj - 1) * w;
             if (x > 0 && m[up + x - 1] != 1) uf_union(lab, me, (unsigned)(up + x - 1));
             if (m[up + x] != 1) uf_union(lab, me, (unsigned)(up + x));
             if (x + 1 < w && m[up + x + 1] != 1) uf_union(lab, me, (unsigned)(up + x + 1));
@@ -462,38 +693,39 @@ __global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map, int h, int w,
+__global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map, int h, int w, int n_frames,
                                                      unsigned* __restrict__ labels, Roi roi,
                                                      const int* __restrict__ roi_rows, uint8_t* __restrict__ edges,
                                                      uint8_t* __restrict__ masked, int* __restrict__ rowcnt) {
-    const int s = blockIdx.z, cw = w >> 4;
-    const int ci = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    int cnt = 0;
-    if (ci < cw) {
-        const size_t off = ((size_t)s * h + y) * w + ci * 16;
-        const uint4 cur4 = *reinterpret_cast<const uint4*>(map + off);
-        uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
-        if (!all_ones16(cur4)) {
-            unsigned* lab = labels + (size_t)s * h * w;
-            int xl, xr;
-            roi_bounds(roi, h, y, roi_rows, xl, xr);
-            const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
-            uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
-            uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
-            for (int q = 0; q < 16; ++q) {
-                if (cur[q] == 1) continue;
-                const int xx = ci * 16 + q;
-                if (!(uf_find(lab, (unsigned)(y * w + xx)) >> 31)) {
-                    e[q] = 255;
-                    if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
-                }
+    const int cw = w >> 4;
+    const long long total = (long long)n_frames * h * cw;
+    const long long ci = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (ci >= total) return;
+    const int s = (int)(ci / ((long long)h * cw));
+    const int r = (int)(ci - (long long)s * h * cw);
+    const int y = r / cw, xb = (r - y * cw) * 16;
+    const size_t off = ((size_t)s * h + y) * w + xb;
+    const uint4 cur4 = *reinterpret_cast<const uint4*>(map + off);
+    uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
+    if (!all_ones16(cur4)) {
+        unsigned* lab = labels + (size_t)s * h * w;
+        int xl, xr, cnt = 0;
+        roi_bounds(roi, h, y, roi_rows, xl, xr);
+        const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
+        uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
+        uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
+        for (int q = 0; q < 16; ++q) {
+            if (cur[q] == 1) continue;
+            const int xx = xb + q;
+            if (!(uf_find(lab, (unsigned)(y * w + xx)) >> 31)) {
+                e[q] = 255;
+                if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
             }
         }
-        if (edges) *reinterpret_cast<uint4*>(edges + off) = e4;
-        *reinterpret_cast<uint4*>(masked + off) = k4;
+        if (cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
     }
-    cnt = wave_sum_i(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
+    if (edges) *reinterpret_cast<uint4*>(edges + off) = e4;
+    *reinterpret_cast<uint4*>(masked + off) = k4;
 }
 
 // ---- L4a: row-major list of edge points -----------------------------------------------------------------------
@@ -546,15 +778,19 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
                                                      HoughCfg cfg, unsigned* __restrict__ nz_all,
                                                      const int* __restrict__ npts, int* __restrict__ accum_all,
                                                      const float* __restrict__ trig, int* __restrict__ segs,
-                                                     int* __restrict__ nseg) {
+                                                     int* __restrict__ nseg, const int* __restrict__ fallback) {
     __shared__ int w_key[3];
     __shared__ int sh_pt[2];
     __shared__ unsigned long long flags[64];           // mask bits of 4096 walk steps
     __shared__ int ends[2][3];                          // x, y, step index of the line end
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (fallback && fallback[s] == 0) return;            // handled by houghp_fast
     uint8_t* mask = masked + (size_t)s * h * w;
     unsigned* nz = nz_all + (size_t)s * h * w;
     int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
+    for (size_t q = tid; q < (size_t)NUMANGLE * numrho; q += 192) accum[q] = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
     const bool th_on = tid < NUMANGLE;
     const float ct = th_on ? trig[2 * tid] : 0.f, sn = th_on ? trig[2 * tid + 1] : 0.f;
     int* arow = accum + (size_t)(th_on ? tid : 0) * numrho + (numrho - 1) / 2;
@@ -687,6 +923,325 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
             }
             if (++nlines >= cfg.max_segments) break;
         }
+    }
+    if (tid == 0) nseg[s] = nlines;
+}
+
+// Fast PPHT: same algorithm and visiting order, restructured for latency.
+//   * the point list and a bitmap of the live edge pixels (bounding rows of the points) sit in LDS, so the
+//     swap-remove draws, the liveness test and the line walks never touch global memory;
+//   * points are voted in speculative batches: up to HB live points are drawn, every theta lane issues the
+//     HB returning atomics back to back (one L2 round trip per batch instead of per point).  The returned
+//     counts are exactly the sequential ones as long as no point of the batch completes a line; at the
+//     first point that does, the later points' votes are rolled back and they are re-examined (liveness
+//     included) after the line has been erased, which is what the sequential loop would have seen.
+// Streams whose points or bitmap do not fit are flagged and handled by houghp_kernel.
+constexpr int HB = 32, NZCAP = 12288, BMWORDS = 16384, FIFO = 128;
+
+__global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, HoughCfg cfg,
+                                                   const unsigned* __restrict__ nz_all, const int* __restrict__ npts,
+                                                   int* __restrict__ accum_all, const float* __restrict__ trig,
+                                                   int* __restrict__ segs, int* __restrict__ nseg,
+                                                   int* __restrict__ fallback) {
+    __shared__ unsigned nz[NZCAP];
+    __shared__ unsigned bm[BMWORDS];
+    __shared__ int fifo[FIFO];             // points drawn from the list but not voted yet (ring buffer)
+    __shared__ int bpt[HB];
+    __shared__ int didx[HB];
+    __shared__ int sh_nb, sh_head, sh_tail, sh_count;
+    __shared__ unsigned w_hit[3];
+    __shared__ int w_key[3];
+    __shared__ unsigned long long flags[8];
+    __shared__ int ends[2][3];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned* nzg = nz_all + (size_t)s * h * w;
+    int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
+    const int total = npts[s];
+    const int ymin = total > 0 ? (int)(nzg[0] >> 16) : 0, ymax = total > 0 ? (int)(nzg[total - 1] >> 16) : 0;
+    const int wpr = (w + 31) >> 5;
+    if (total > NZCAP || (ymax - ymin + 1) * wpr > BMWORDS || cfg.line_gap < 1) {
+        if (tid == 0) fallback[s] = 1;
+        return;
+    }
+    if (tid == 0) fallback[s] = 0, sh_head = 0, sh_tail = 0, sh_count = total;
+    for (int i = tid; i < (ymax - ymin + 1) * wpr; i += 192) bm[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < total; i += 192) {
+        const unsigned p = nzg[i];
+        nz[i] = p;
+        const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+        atomicOr(&bm[(y - ymin) * wpr + (x >> 5)], 1u << (x & 31));
+    }
+    __syncthreads();
+    auto live = [&](int x, int y) -> bool {
+        return y >= ymin && y <= ymax && x >= 0 && x < w && ((bm[(y - ymin) * wpr + (x >> 5)] >> (x & 31)) & 1u);
+    };
+    const bool th_on = tid < NUMANGLE;
+    const float ct = th_on ? trig[2 * tid] : 0.f, sn = th_on ? trig[2 * tid + 1] : 0.f;
+    int* arow = accum + (size_t)(th_on ? tid : 0) * numrho + (numrho - 1) / 2;
+    // Zero the part of the accumulator this frame can touch (rho range of the points' bounding box per
+    // theta, +-2 bins for float rounding).  Doing it here instead of a device-wide memset also leaves the
+    // lines in this XCD's L2, where the vote atomics execute.
+    {
+        int xmn = w, xmx = 0;
+        for (int i = tid; i < total; i += 192) {
+            const int x = (int)(nz[i] & 0xffffu);
+            xmn = x < xmn ? x : xmn, xmx = x > xmx ? x : xmx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const int a = __shfl_xor(xmn, off, 64), b = __shfl_xor(xmx, off, 64);
+            xmn = a < xmn ? a : xmn, xmx = b > xmx ? b : xmx;
+        }
+        if (lane == 0) w_key[wid] = xmn, w_hit[wid] = (unsigned)xmx;
+        __syncthreads();
+        xmn = min(w_key[0], min(w_key[1], w_key[2]));
+        xmx = (int)max(w_hit[0], max(w_hit[1], w_hit[2]));
+        __syncthreads();
+        const int half = (numrho - 1) / 2;
+        for (int n = 0; n < NUMANGLE; ++n) {
+            const float c = trig[2 * n], sv = trig[2 * n + 1];
+            const float r0 = (float)xmn * c + (float)ymin * sv, r1 = (float)xmn * c + (float)ymax * sv;
+            const float r2 = (float)xmx * c + (float)ymin * sv, r3 = (float)xmx * c + (float)ymax * sv;
+            int lo = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
+            int hi = __float2int_rn(fmaxf(fmaxf(r0, r1), fmaxf(r2, r3))) + 2;
+            lo = lo < -half ? -half : lo, hi = hi > half ? half : hi;
+            int* row = accum + (size_t)n * numrho + half;
+            for (int r = lo + tid; r <= hi; r += 192) row[r] = 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    unsigned long long rng = ~0ull;        // advanced identically by every lane of wave 0
+    int nlines = 0;
+    const int shift = 16;
+    // wave 0: draw up to HB more points from the list into the FIFO (cv::RNG order, swap-remove).
+    // The generator is stepped by all lanes (cheap), the modulo is taken lane-parallel, only the
+    // swap-remove chain itself is sequential.
+    auto top_up = [&]() {
+        const int cnt = sh_count, fill = sh_tail - sh_head;
+        int nd = FIFO - HB - fill;                // keep room for a rolled-back batch tail (< HB entries)
+        nd = nd < HB ? nd : HB;
+        nd = nd < cnt ? nd : cnt;
+        if (nd <= 0) return;
+        unsigned r_mine = 0;
+        for (int k = 0; k < nd; ++k) {
+            rng = (unsigned long long)(unsigned)rng * 4164903690ull + (unsigned)(rng >> 32);
+            if (k == lane) r_mine = (unsigned)rng;
+        }
+        if (lane < nd) didx[lane] = (int)(r_mine % (unsigned)(cnt - lane));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        if (lane == 0) {
+            const int tail = sh_tail;
+            for (int k = 0; k < nd; ++k) {
+                const int idx = didx[k];
+                fifo[(tail + k) & (FIFO - 1)] = (int)nz[idx];
+                nz[idx] = nz[cnt - 1 - k];
+            }
+            sh_tail = tail + nd, sh_count = cnt - nd;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    };
+    if (wid == 0) top_up();
+    __syncthreads();
+    for (;;) {
+        // ---- form the batch: pop up to HB points that are still live (wave 0) -------------------------------------
+        if (wid == 0) {
+            int head = sh_head;
+            int nb = 0;
+            for (;;) {
+                const int avail = sh_tail - head;
+                if (avail == 0) {
+                    if (sh_count == 0) break;
+                    sh_head = head;                       // publish before top_up reads it
+                    __builtin_amdgcn_wave_barrier();
+                    top_up();
+                    continue;
+                }
+                const int take = avail < (HB - nb) ? avail : (HB - nb);     // <= 32 <= wave
+                int p = 0;
+                bool ok = false;
+                if (lane < take) {
+                    p = fifo[(head + lane) & (FIFO - 1)];
+                    ok = live(p & 0xffff, p >> 16);
+                }
+                const unsigned long long okb = __ballot(ok);
+                if (ok) bpt[nb + __popcll(okb & ((1ull << lane) - 1ull))] = p;
+                nb += __popcll(okb);
+                head += take;
+                if (nb == HB) break;
+            }
+            if (lane == 0) sh_head = head, sh_nb = nb;
+        }
+        __syncthreads();
+        const int nb = sh_nb;
+        if (nb == 0) break;                 // list and FIFO exhausted
+        // ---- speculative votes; wave 0 refills the FIFO while the atomics are in flight ----------------------------
+        int val[HB];
+        unsigned hitbits = 0;
+        // branch-free so the HB returning atomics issue back to back (a predicated block per vote makes the
+        // compiler wait for each result in turn): slots past nb and lanes past theta 179 add 0.
+        int pts[HB];
+#pragma unroll
+        for (int b = 0; b < HB; ++b) pts[b] = bpt[b < nb ? b : 0];
+#pragma unroll
+        for (int b = 0; b < HB; ++b) {
+            const int r = __float2int_rn((float)(pts[b] & 0xffff) * ct + (float)(pts[b] >> 16) * sn);
+            val[b] = atomicAdd(&arow[r], (b < nb && th_on) ? 1 : 0);
+        }
+        if (wid == 0) top_up();
+#pragma unroll
+        for (int b = 0; b < HB; ++b) val[b] = (b < nb && th_on) ? val[b] + 1 : 0;
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+            if (__ballot(b < nb && th_on && val[b] >= cfg.threshold) != 0ull) hitbits |= 1u << b;
+        if (lane == 0) w_hit[wid] = hitbits;
+        __syncthreads();
+        const unsigned hits = w_hit[0] | w_hit[1] | w_hit[2];
+        if (hits == 0) {
+            __syncthreads();
+            continue;
+        }
+        const int bs = __ffs((int)hits) - 1;
+        int kv = 0;
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+            if (b == bs) kv = val[b];
+        int key = th_on ? ((kv << 8) | (255 - tid)) : -1;
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if (lane == 0) w_key[wid] = key;
+        // roll back the votes of the points after bs; they are re-examined after the line is erased
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+            if (b > bs && b < nb && th_on) {
+                const int p = bpt[b];
+                atomicSub(&arow[__float2int_rn((float)(p & 0xffff) * ct + (float)(p >> 16) * sn)], 1);
+            }
+        __syncthreads();
+        if (tid == 0) {
+            // the points after bs go back to the FRONT of the FIFO (they were drawn before everything in it)
+            int head = sh_head;
+            for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
+            sh_head = head;
+        }
+        int best = w_key[0] > w_key[1] ? w_key[0] : w_key[1];
+        best = best > w_key[2] ? best : w_key[2];
+        const int max_n = 255 - (best & 255);
+        const int j = bpt[bs] & 0xffff, i = bpt[bs] >> 16;
+        // ---- walk along the line in both directions (LDS bitmap) ------------------------------------------------
+        const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
+        int x0 = j, y0 = i, dx0, dy0, xflag;
+        if (fabsf(a) > fabsf(b)) {
+            xflag = 1;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(b * (float)(1 << shift) / fabsf(a));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = 0;
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = __float2int_rn(a * (float)(1 << shift) / fabsf(b));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        if (tid < 6) ends[tid / 3][tid % 3] = 0;
+        __syncthreads();
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            int gap = 0, et = 0;
+            bool done = false;
+            for (int t0 = 0; !done; t0 += 192) {
+                const int t = t0 + tid;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                const bool on = inb && live(j1, i1);
+                const unsigned long long bon = __ballot(on), bin = __ballot(inb);
+                if (lane == 0) flags[wid] = bon, flags[4 + wid] = bin;
+                __syncthreads();
+                // replay the gap rule on the 192 flag bits, word by word (line_gap >= 1)
+                for (int wq = 0; wq < 3 && !done; ++wq) {
+                    unsigned long long fo = flags[wq];
+                    const unsigned long long fi = flags[4 + wq];
+                    const int nin = fi == ~0ull ? 64 : __ffsll((long long)~fi) - 1;      // in-bounds steps of this word
+                    int pos = 0;                                                          // steps consumed
+                    while (pos < nin) {
+                        const unsigned long long rest = fo >> pos;
+                        if (rest == 0ull) {                                               // only gaps remain
+                            const int zeros = nin - pos;
+                            if (gap + zeros > cfg.line_gap) done = true;
+                            gap += zeros;
+                            pos = nin;
+                            break;
+                        }
+                        const int z = __ffsll((long long)rest) - 1;                       // zeros before the next hit
+                        if (z >= nin - pos) {
+                            const int zeros = nin - pos;
+                            if (gap + zeros > cfg.line_gap) done = true;
+                            gap += zeros;
+                            pos = nin;
+                            break;
+                        }
+                        if (gap + z > cfg.line_gap) { done = true; break; }
+                        pos += z;
+                        gap = 0;
+                        et = t0 + wq * 64 + pos;
+                        ++pos;
+                    }
+                    if (nin < 64) done = true;                                            // left the image
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const int xx = x0 + et * dx, yy = y0 + et * dy;
+                ends[k][0] = xflag ? xx : xx >> shift, ends[k][1] = xflag ? yy >> shift : yy, ends[k][2] = et;
+            }
+        }
+        __syncthreads();
+        const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
+        const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            const int tend = ends[k][2];
+            for (int t0 = 0; t0 <= tend; t0 += 192) {
+                const int t = t0 + tid;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool on = t <= tend && live(j1, i1);
+                const unsigned long long bon = __ballot(on);
+                if (lane == 0) flags[wid] = bon;
+                __syncthreads();
+                if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
+                if (good && th_on) {
+                    for (int wq = 0; wq < 3; ++wq) {
+                        unsigned long long bits = flags[wq];
+                        while (bits) {
+                            const int q = __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int tt = t0 + wq * 64 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
+                            int ii, jj;
+                            if (xflag) jj = xx, ii = yy >> shift; else jj = xx >> shift, ii = yy;
+                            atomicSub(&arow[__float2int_rn((float)jj * ct + (float)ii * sn)], 1);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (good) {
+            if (tid == 0) {
+                int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
+                o[0] = e0x, o[1] = e0y, o[2] = e1x, o[3] = e1y;
+            }
+            if (++nlines >= cfg.max_segments) break;
+        }
+        __syncthreads();
     }
     if (tid == 0) nseg[s] = nlines;
 }
@@ -889,23 +1444,28 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* nseg = (int*)(ws + L.nseg);
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
     const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0;
-    if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+    const bool streamp = (w % 4 == 0) && w >= 8 && (((size_t)bgr | (size_t)workspace) & 15) == 0 && !(stages & 4);
+    const dim3 sgrid((w + SW - 1) / SW, (h + 4 * SROWS - 1) / (4 * SROWS), n_streams);
+    if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
+    else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
     else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
     AV_LAUNCH_CHECK();
-    if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+    if (streamp) hipLaunchKernelGGL(sobel_nms_stream, sgrid, dim3(256), 0, st, blur, h, w, thr, map, labels);
+    else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
     else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
     AV_LAUNCH_CHECK();
-    const dim3 chunks(((w >> 4) + 255) / 256, h, n_streams);
-    if (fastp) hipLaunchKernelGGL(ccl_merge_fast, chunks, dim3(256), 0, st, map, h, w, labels);
+    const long long nchunks = (long long)n_streams * h * (w >> 4);
+    const dim3 chunks((unsigned)((nchunks + 255) / 256));
+    if (fastp) hipLaunchKernelGGL(ccl_merge_fast, chunks, dim3(256), 0, st, map, h, w, n_streams, labels);
     else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
     AV_LAUNCH_CHECK();
     Roi roi;
     roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
     roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
     if (fastp)
-        hipLaunchKernelGGL(finalize_fast, chunks, dim3(256), 0, st, map, h, w, labels, roi, roi_rows,
+        hipLaunchKernelGGL(finalize_fast, chunks, dim3(256), 0, st, map, h, w, n_streams, labels, roi, roi_rows,
                            (stages & 1) ? edges : nullptr, masked, rowcnt);
     else
         hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
@@ -915,11 +1475,16 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     AV_LAUNCH_CHECK();
     if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)
     HoughCfg hc{cfg->hough_threshold, cfg->min_line_length, cfg->max_line_gap, cfg->max_segments};
+    int* fb = rowcnt;       // the per-row counters are dead after compaction: reuse [s*h] as the fallback flag
+    const bool use_fast = !(stages & 8);
+    if (use_fast) {
+        hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
+                           segs, nseg, fb);
+        AV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
-                       lc->d_trig, segs, nseg);
+                       lc->d_trig, segs, nseg, use_fast ? fb : nullptr);
     AV_LAUNCH_CHECK();
-    // the accumulator must be all zeros again for the next frame (PPHT leaves residual and negative votes)
-    AV_HIP(hipMemsetAsync(accum, 0, (size_t)n_streams * NUMANGLE * L.numrho * 4, st));
     hipLaunchKernelGGL(lane_fit_kernel, dim3((n_streams * 2 + 63) / 64), dim3(64), 0, st, n_streams, h, w,
                        cfg->max_segments, cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);
     AV_LAUNCH_CHECK();

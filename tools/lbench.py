@@ -23,7 +23,7 @@ nat.check(L.av_lane_workspace_init(ctx.handle, sh, S, h, w, MS, nat.ptr(ws)))
 state = torch.zeros(S, 8, dtype=torch.float64, device=dev); poly = torch.zeros(S, 2, 3, dtype=torch.float64, device=dev)
 pts = torch.zeros(S, 2, 50, 2, dtype=torch.int32, device=dev); info = torch.zeros(S, 8, dtype=torch.int32, device=dev)
 conf = torch.zeros(S, 2, dtype=torch.float64, device=dev)
-cfg = nat.LaneCfg(50, 50, 150, MS, 0.7)
+cfg = nat.LaneCfg(int(os.environ.get("HT", "50")), 50, 150, MS, 0.7)
 def run(stages):
     nat.check(L.av_lane_detect(ctx.handle, sh, C.byref(cfg), S, h, w, nat.ptr(frames), None, nat.ptr(ws), nat.ptr(state),
                                nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), stages))
