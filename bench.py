@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"])
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default by workload)")
     ap.add_argument("--window", type=int, default=None, help="frames per stream per step")
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph")
@@ -50,6 +50,69 @@ def cpu_baseline(seconds):
     return {"value": round(fps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the single-stream 1280x720 simulated-detection loop (detect+track+KF+plan), "
                       "NumPy oracle, 1 thread" % n}
+
+
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF
+
+
+def bench_config3(a, world, rank, local):
+    """YOLO-mode detector (random-init YOLOv8n topology, bf16 MFMA convs) + lane detector on frames generated
+    on the device.  step = one frame of each of `streams` cameras."""
+    import torch
+    import torch.distributed as dist
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import PerceptionLoop
+    S = a.streams or 64
+    loop = PerceptionLoop(n_streams=S, device=local)
+    L = nat.lib()
+    evs = [[C.c_void_p(), C.c_void_p()] for _ in range(a.steps)]
+    for e in evs:
+        nat.check(L.av_event_create(C.byref(e[0])))
+        nat.check(L.av_event_create(C.byref(e[1])))
+    for _ in range(a.warmup):
+        loop.step()
+    loop.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        loop.enqueue_generate(stream0=rank * S)
+        nat.check(L.av_event_record(evs[k][0], loop._s))
+        loop.enqueue_detect()
+        nat.check(L.av_event_record(evs[k][1], loop._s))
+        loop.enqueue_lanes()
+    loop.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = C.c_float()
+    tot = 0.0
+    for e in evs:
+        nat.check(L.av_event_elapsed_ms(e[0], e[1], C.byref(ms)))
+        tot += ms.value
+    det_ms = tot / a.steps
+    tfl = loop.flops_per_frame * S / (det_ms * 1e-3) / 1e12
+    if rank == 0:
+        out = {"metric": "end-to-end frames/sec (1280x720 synthetic)", "value": round(S * a.steps * world / el, 1),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (generated on device)",
+               "config": {"workload": "config3: %d camera streams/GPU, 1280x720, YOLO-mode detector (random-init YOLOv8n "
+                                      "topology, letterbox 384x640) + Canny/Hough lane detector" % S,
+                          "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
+               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (63 launches per forward, timed with decode+NMS)",
+                            "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "flops_per_launch": int(loop.flops_per_frame * S), "avg_launch_ms": round(det_ms, 4)}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -74,6 +137,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    if a.workload == "config3":
+        return bench_config3(a, world, rank, local)
     from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
     from multimodal_autonomous_driving_perception_and_planning_amd.distributed import TrackTableExchange
     from oracle.harness_ref import ego_motion

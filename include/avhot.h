@@ -257,6 +257,13 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
  * numbers, 0 = network input; 100+2i / 101+2i = float32 box / class logits of level i). */
 int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff);
 
+/* ---- synthetic input ---------------------------------------------------
+ * Deterministic 8-bit BGR road scenes generated on the device, standing in for the reference's lost
+ * SyntheticDataGenerator (data/generators, source absent).  Frame (stream0+s, frame) is bit-identical to
+ * oracle/lane_ref.py: synthetic_frame().   bgr: u8 [n_streams][h][w][3] */
+int av_synth_frames(av_ctx* ctx, av_stream_t stream, int n_streams, int h, int w, int stream0, int frame,
+                    uint8_t* bgr);
+
 #ifdef __cplusplus
 }
 #endif

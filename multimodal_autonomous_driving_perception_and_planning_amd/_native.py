@@ -80,6 +80,7 @@ _SIGS = [
     ("av_lane_workspace_init", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_lane_workspace_view", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_size_t)]),
+    ("av_synth_frames", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_yolo_param_count", C.c_size_t, []),
     ("av_yolo_create", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),
     ("av_yolo_destroy", C.c_int, [vp]),

@@ -186,3 +186,92 @@ class HotLoop:
     def planner_bytes_per_state(self):
         c, n = self.n_cand, self.n_points
         return 32 + c * n * 48 + c * 8 + c * 4
+
+
+class PerceptionLoop:
+    """BASELINE config 3: S camera streams, frames generated on the device, YOLO-mode detector (MFMA conv
+    path) + lane detector per frame.  Everything stays in HBM; one enqueue per stage per step."""
+
+    def __init__(self, n_streams=16, h=720, w=1280, device=0, model="random:0", max_segments=512, ctx=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("PerceptionLoop needs a HIP device; this package has no CPU path")
+        from .perception.yolo import MAX_DET, YoloV8n, conv_specs
+        self.S, self.h, self.w, self.ms = n_streams, h, w, max_segments
+        self.dev = torch.device("cuda", device)
+        self.L = nat.lib()
+        self.yolo = YoloV8n(model, device=device, batch=n_streams)
+        self.ctx = self.yolo._dev.ctx
+        self.yolo._prepare(h, w)
+        self.stream = torch.cuda.Stream(device=self.dev)
+        S, d = n_streams, self.dev
+        self.frames = torch.empty(S, h, w, 3, dtype=torch.uint8, device=d)
+        self.ws = torch.empty(int(self.L.av_lane_workspace_bytes(S, h, w, max_segments)), dtype=torch.uint8, device=d)
+        nat.check(self.L.av_lane_workspace_init(self.ctx.handle, self._s, S, h, w, max_segments, nat.ptr(self.ws)))
+        self.lane_state = torch.zeros(S, 8, dtype=torch.float64, device=d)
+        self.poly = torch.zeros(S, 2, 3, dtype=torch.float64, device=d)
+        self.pts = torch.zeros(S, 2, 50, 2, dtype=torch.int32, device=d)
+        self.info = torch.zeros(S, 8, dtype=torch.int32, device=d)
+        self.conf = torch.zeros(S, 2, dtype=torch.float64, device=d)
+        self.det_n = torch.zeros(S, dtype=torch.int32, device=d)
+        self.det_box = torch.zeros(S, MAX_DET, 4, dtype=torch.float32, device=d)
+        self.det_conf = torch.zeros(S, MAX_DET, dtype=torch.float32, device=d)
+        self.det_cls = torch.zeros(S, MAX_DET, dtype=torch.int32, device=d)
+        self.lcfg = nat.LaneCfg(50, 50, 150, max_segments, 0.7)
+        self.max_det = MAX_DET
+        net_h, net_w, _ = self.yolo.dims()
+        # 2*MACs of every convolution at the letterboxed resolution (the figure the MFMA roofline is priced on)
+        fl, hh, ww = 0, net_h, net_w
+        sizes = []
+        for cin, cout, k, s, _ in conv_specs():
+            sizes.append((cin, cout, k, s))
+        self.flops_per_frame = _yolo_flops(net_h, net_w)
+        self.frame_idx = 0
+        self.stream.synchronize()
+
+    @property
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def enqueue_generate(self, stream0=0):
+        nat.check(self.L.av_synth_frames(self.ctx.handle, self._s, self.S, self.h, self.w, stream0, self.frame_idx,
+                                         nat.ptr(self.frames)))
+        self.frame_idx += 1
+
+    def enqueue_detect(self):
+        nat.check(self.L.av_yolo_forward(self.yolo._h, self._s, nat.ptr(self.frames), 0.25, 0.7, self.max_det,
+                                         nat.ptr(self.det_n), nat.ptr(self.det_box), nat.ptr(self.det_conf),
+                                         nat.ptr(self.det_cls)))
+
+    def enqueue_lanes(self):
+        nat.check(self.L.av_lane_detect(self.ctx.handle, self._s, C.byref(self.lcfg), self.S, self.h, self.w,
+                                        nat.ptr(self.frames), None, nat.ptr(self.ws), nat.ptr(self.lane_state),
+                                        nat.ptr(self.poly), nat.ptr(self.pts), nat.ptr(self.info), nat.ptr(self.conf), 0))
+
+    def step(self, sync=False):
+        self.enqueue_generate()
+        self.enqueue_detect()
+        self.enqueue_lanes()
+        if sync:
+            self.stream.synchronize()
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+def _yolo_flops(H, W):
+    """2*MACs of the YOLOv8n graph at input H x W (per frame), walking the same layer list as the library."""
+    from .perception.yolo import conv_specs
+    specs = conv_specs()
+    # spatial size of every conv's OUTPUT, in execution order
+    def c2f(n):
+        return [0] * (2 + 2 * n)
+    div = []
+    div += [2, 4] + [4] * 4 + [8] + [8] * 6 + [16] + [16] * 6 + [32] + [32] * 4 + [32, 32]     # backbone + SPPF
+    div += [16] * 4 + [8] * 4 + [16] + [16] * 4 + [32] + [32] * 4                                # head
+    for d in (8, 16, 32):
+        div += [d] * 6
+    assert len(div) == len(specs)
+    fl = 0
+    for (cin, cout, k, s, _), d in zip(specs, div):
+        fl += 2 * cin * cout * k * k * (H // d) * (W // d)
+    return fl
