@@ -247,63 +247,62 @@ __global__ void __launch_bounds__(1024) nms_sort_kernel(int A, float conf_thres,
     }
 }
 
-// 64x64 blocks of the suppression relation as bit masks (torchvision-style)
-__global__ void __launch_bounds__(64) nms_mask_kernel(int A, int words, float iou_thres, const float* __restrict__ sbox,
-                                                      const int* __restrict__ scount, unsigned long long* __restrict__ mask) {
-    const int n = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x, cnt = scount[n];
-    if (rb * 64 >= cnt || cb * 64 >= cnt || cb < rb) return;
-    __shared__ float cbx[64][4];
-    const int t = threadIdx.x;
-    const int cj = cb * 64 + t;
-    if (cj < cnt) {
-        const float* b = sbox + ((size_t)n * A + cj) * 4;
-        cbx[t][0] = b[0], cbx[t][1] = b[1], cbx[t][2] = b[2], cbx[t][3] = b[3];
-    }
-    __syncthreads();
-    const int ri = rb * 64 + t;
-    if (ri >= cnt) return;
-    const float* a = sbox + ((size_t)n * A + ri) * 4;
-    const float ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3], aa = (ax2 - ax1) * (ay2 - ay1);
-    unsigned long long bits = 0;
-    const int lim = (cnt - cb * 64) < 64 ? (cnt - cb * 64) : 64;
-    for (int j = (rb == cb ? t + 1 : 0); j < lim; ++j) {
-        const float xx1 = fmaxf(ax1, cbx[j][0]), yy1 = fmaxf(ay1, cbx[j][1]);
-        const float xx2 = fminf(ax2, cbx[j][2]), yy2 = fminf(ay2, cbx[j][3]);
-        const float inter = fmaxf(xx2 - xx1, 0.f) * fmaxf(yy2 - yy1, 0.f);
-        const float ab = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
-        if (inter / (aa + ab - inter) > iou_thres) bits |= 1ull << j;
-    }
-    mask[((size_t)n * A + ri) * words + cb] = bits;
-}
-
-// sequential scan over the sorted candidates (one wave per image); also maps boxes back to the frame
-__global__ void __launch_bounds__(128) nms_scan_kernel(int A, int words, int max_det, const unsigned long long* __restrict__ mask,
-                                                       const int* __restrict__ scount, const int* __restrict__ sidx,
-                                                       const float* __restrict__ cbox, const float* __restrict__ cconf,
-                                                       const int* __restrict__ ccls, float gain, float padx, float pady,
-                                                       float fw, float fh, int* __restrict__ det_n, float* __restrict__ det_box,
-                                                       float* __restrict__ det_conf, int* __restrict__ det_cls) {
-    __shared__ unsigned long long removed[128];
+// Greedy class-aware NMS, one workgroup per image (torchvision.ops.nms semantics on the sorted, class-offset
+// boxes).  The sorted boxes sit in LDS; only boxes that are KEPT are ever compared against the rest
+// (<= max_det rows of the suppression relation instead of all of it), and the next survivor is found by
+// scanning the removed bitmap.  Also maps the kept boxes back to the frame (scale_boxes) and truncation
+// is left to the caller (detector.py:111).
+__global__ void __launch_bounds__(1024) nms_greedy_kernel(int A, int max_det, float iou_thres, const float* __restrict__ sbox,
+                                                          const int* __restrict__ scount, const int* __restrict__ sidx,
+                                                          const float* __restrict__ cbox, const float* __restrict__ cconf,
+                                                          const int* __restrict__ ccls, float gain, float padx, float pady,
+                                                          float fw, float fh, int* __restrict__ det_n,
+                                                          float* __restrict__ det_box, float* __restrict__ det_conf,
+                                                          int* __restrict__ det_cls) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+    float4* bx = reinterpret_cast<float4*>(nms_smem);                       // [cnt]
+    unsigned* removed = reinterpret_cast<unsigned*>(bx + A);                 // [(A+31)/32]
+    __shared__ int cur;
     const int n = blockIdx.x, t = threadIdx.x, cnt = scount[n];
-    removed[t] = 0;
+    const int words = (cnt + 31) >> 5;
+    for (int i = t; i < cnt; i += 1024) bx[i] = reinterpret_cast<const float4*>(sbox)[(size_t)n * A + i];
+    for (int i = t; i < words; i += 1024) removed[i] = 0;
+    if (t == 0) cur = 0;
     __syncthreads();
     int kept = 0;
-    for (int i = 0; i < cnt && kept < max_det; ++i) {
-        const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;      // uniform
-        __syncthreads();
-        if (dead) continue;
+    while (kept < max_det) {
+        // next candidate that is still alive (thread 0 scans the bitmap from `cur`)
         if (t == 0) {
-            const int a = sidx[(size_t)n * A + i];
-            const float* b = cbox + ((size_t)n * A + a) * 4;
+            int i = cur;
+            while (i < cnt) {
+                const unsigned wv = ~removed[i >> 5] & (~0u << (i & 31));
+                if (wv) { i = (i & ~31) + __ffs((int)wv) - 1; break; }
+                i = (i & ~31) + 32;
+            }
+            cur = i < cnt ? i : cnt;
+        }
+        __syncthreads();
+        const int i = cur;
+        if (i >= cnt) break;
+        const float4 a = bx[i];
+        const float aa = (a.z - a.x) * (a.w - a.y);
+        for (int j = i + 1 + t; j < cnt; j += 1024) {
+            const float4 b = bx[j];
+            const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+            const float inter = fmaxf(xx2 - xx1, 0.f) * fmaxf(yy2 - yy1, 0.f);
+            if (inter / (aa + (b.z - b.x) * (b.w - b.y) - inter) > iou_thres) atomicOr(&removed[j >> 5], 1u << (j & 31));
+        }
+        if (t == 0) {
+            const int an = sidx[(size_t)n * A + i];
+            const float* b = cbox + ((size_t)n * A + an) * 4;
             float* o = det_box + ((size_t)n * max_det + kept) * 4;
             o[0] = fminf(fmaxf((b[0] - padx) / gain, 0.f), fw), o[1] = fminf(fmaxf((b[1] - pady) / gain, 0.f), fh);
             o[2] = fminf(fmaxf((b[2] - padx) / gain, 0.f), fw), o[3] = fminf(fmaxf((b[3] - pady) / gain, 0.f), fh);
-            det_conf[(size_t)n * max_det + kept] = cconf[(size_t)n * A + a];
-            det_cls[(size_t)n * max_det + kept] = ccls[(size_t)n * A + a];
+            det_conf[(size_t)n * max_det + kept] = cconf[(size_t)n * A + an];
+            det_cls[(size_t)n * max_det + kept] = ccls[(size_t)n * A + an];
+            cur = i + 1;
         }
         ++kept;
-        const int w0 = i >> 6;
-        if (t >= w0 && t < words) removed[t] |= mask[((size_t)n * A + i) * words + t];
         __syncthreads();
     }
     if (t == 0) det_n[n] = kept;
@@ -389,7 +388,7 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     a.res = nullptr, a.res_cs = 0, a.res_coff = 0;
     if (res) a.res = y.bufs[res->buf].p, a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
     a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
-    op.mt = (cout % 64 == 0) ? 4 : ((cout % 32 == 0) ? 2 : 1);
+    op.mt = (cout % 64 == 0) ? 4 : ((cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1));
     y.ops.push_back(op);
     return true;
 }
@@ -508,11 +507,9 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
 #undef CV
     ok = ok && y.wpos == y.wtotal && y.A <= MAX_CAND;
     y.words = (y.A + 63) / 64;
-    ok = ok && y.words <= 128;
     ok = ok && dev_alloc(y, (void**)&y.cbox, (size_t)batch * y.A * 16) && dev_alloc(y, (void**)&y.cconf, (size_t)batch * y.A * 4) &&
          dev_alloc(y, (void**)&y.ccls, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.sbox, (size_t)batch * y.A * 16) &&
-         dev_alloc(y, (void**)&y.sidx, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.scount, (size_t)batch * 4) &&
-         dev_alloc(y, (void**)&y.mask, (size_t)batch * y.A * y.words * 8);
+         dev_alloc(y, (void**)&y.sidx, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.scount, (size_t)batch * 4);
     y.named = {{0, Slice{x0, 0, 8}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
                {6, Slice{cat11, 256, 128}}, {8, Slice{b8, 0, 256}}, {9, Slice{cat20, 128, 256}}, {12, Slice{cat17, 64, 128}},
                {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}};
@@ -522,6 +519,9 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         av_set_error("av_yolo_create: graph construction failed (parameter blob / capacity mismatch)");
         return AV_EINVAL;
     }
+    // the NMS kernel keeps all sorted boxes in LDS (16 B each): above the default 64 KB dynamic limit
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((size_t)y.A * 16 + (size_t)((y.A + 31) / 32) * 4 + 16)));
     (void)hipDeviceSynchronize();
     *out = h;
     return AV_OK;
@@ -571,6 +571,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             constexpr int NT = 2;
             const dim3 grid((a.npix + 16 * NT * 4 - 1) / (16 * NT * 4), a.cout / (16 * op.mt));
             if (op.mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, NT>), grid, dim3(256), 0, st, a);
+            else if (op.mt == 5) hipLaunchKernelGGL((conv_mfma_kernel<5, NT>), grid, dim3(256), 0, st, a);
             else if (op.mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<2, NT>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_mfma_kernel<1, NT>), grid, dim3(256), 0, st, a);
         } else {
@@ -599,13 +600,12 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, st, y.A, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
     AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(y.words, y.words, B), dim3(64), 0, st, y.A, y.words, iou_thres, y.sbox, y.scount, y.mask);
-    AV_LAUNCH_CHECK();
     // gain/pad of ultralytics scale_boxes
     const float gain = std::fmin((float)y.H / y.inH, (float)y.W / y.inW);
     const float padx = (float)std::lround((y.W - y.inW * gain) / 2 - 0.1), pady = (float)std::lround((y.H - y.inH * gain) / 2 - 0.1);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(128), 0, st, y.A, y.words, max_det, y.mask, y.scount, y.sidx, y.cbox, y.cconf,
-                       y.ccls, gain, padx, pady, (float)y.inW, (float)y.inH, det_n, det_box, det_conf, det_cls);
+    const size_t nms_lds = (size_t)y.A * 16 + (size_t)((y.A + 31) / 32) * 4 + 16;
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(1024), nms_lds, st, y.A, max_det, iou_thres, y.sbox, y.scount, y.sidx,
+                       y.cbox, y.cconf, y.ccls, gain, padx, pady, (float)y.inW, (float)y.inH, det_n, det_box, det_conf, det_cls);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
