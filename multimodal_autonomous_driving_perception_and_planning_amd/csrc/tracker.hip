@@ -168,13 +168,24 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         int best_j = -1;
         double ious[DREG > 0 ? DREG : 1];
         if (DREG > 0) {
+            // all detection boxes of the frame in one batch of LDS reads (uniform addresses), then a
+            // branch-free IoU pass: slots >= nd and rows >= T get -1
+            int4 db[DREG > 0 ? DREG : 1];
+#pragma unroll
+            for (int j = 0; j < (DREG > 0 ? DREG : 1); ++j)
+                db[j] = *reinterpret_cast<const int4*>(dbox + (j < dcap ? j : 0) * 4);
             const double a1 = (double)(r.x2 - r.x1) * (double)(r.y2 - r.y1);
 #pragma unroll
             for (int j = 0; j < (DREG > 0 ? DREG : 1); ++j) {
-                double v = -1.0;
-                if (active && j < nd)
-                    v = iou_fast(r.x1, r.y1, r.x2, r.y2, a1, dbox[j * 4 + 0], dbox[j * 4 + 1], dbox[j * 4 + 2], dbox[j * 4 + 3]);
-                ious[j] = (v >= cfg.iou_threshold) ? v : -1.0;          // :147  pairs below thr can never be picked
+                const int xi1 = r.x1 > db[j].x ? r.x1 : db[j].x, yi1 = r.y1 > db[j].y ? r.y1 : db[j].y;
+                const int xi2 = r.x2 < db[j].z ? r.x2 : db[j].z, yi2 = r.y2 < db[j].w ? r.y2 : db[j].w;
+                const int iw = xi2 - xi1, ih = yi2 - yi1;
+                const double inter = (double)iw * (double)ih;
+                const double a2 = (double)(db[j].z - db[j].x) * (double)(db[j].w - db[j].y);
+                const double uni = a1 + a2 - inter;
+                double v = (iw > 0 && ih > 0 && uni > 0.0) ? inter / uni : 0.0;     // :95-105
+                v = (v >= cfg.iou_threshold) ? v : -1.0;                              // :147  never picked below thr
+                ious[j] = (active && j < nd) ? v : -1.0;
             }
         }
         auto recompute = [&]() {
