@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -108,6 +109,93 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
             if (a.act)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.0f + __expf(-v[q]));              // SiLU
+            if (a.res) {
+                const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
+                v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
+            }
+            if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                *reinterpret_cast<ushort4*>(a.out + p * a.out_cs + a.out_coff + ch) =
+                    make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+        }
+    }
+}
+
+// LDS-tiled variant for Cin % 32 == 0 (all but the first few layers).  A workgroup (4 waves) owns an 8x16
+// output tile of one image and 16*MT output channels.  Per 32-channel chunk of the input it stages
+//   patch [PH*PW pixels][32 ch]   (the tile's receptive field incl. halo, zero outside the image)
+//   wts   [16*MT rows][taps*32]   (this chunk's slice of the folded weights)
+// in LDS with 16 bytes of padding per pixel / row (80- and 592-byte strides: every ds_read_b128 of a
+// 16-lane group lands on distinct banks), then runs taps MFMA steps per chunk entirely out of LDS: the
+// input is fetched once per tile instead of once per tap and the weights once per workgroup instead of
+// once per wave.  Wave w computes output rows 2w, 2w+1 of the tile (16 columns each).
+constexpr int LT_H = 8, LT_W = 16, LT_CK = 32, LT_PIXB = LT_CK * 2 + 16;
+
+template <int MT>
+__global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int taps = a.ksz * a.ksz, pad = a.ksz >> 1, s = a.stride;
+    const int PH = (LT_H - 1) * s + a.ksz, PW = (LT_W - 1) * s + a.ksz;
+    const int wrowb = taps * LT_CK * 2 + 16;
+    unsigned char* patch = lsm;
+    unsigned char* wts = lsm + (((size_t)PH * PW * LT_PIXB + 15) & ~size_t(15));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int oy0 = ty * LT_H, ox0 = tx * LT_W;
+    const int ch_base = blockIdx.y * 16 * MT;
+    const int iy_org = oy0 * s - pad, ix_org = ox0 * s - pad;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
+        __syncthreads();
+        for (int i = tid; i < PH * PW * 4; i += 256) {
+            const int pix = i >> 2, part = i & 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy_org + py, ix = ix_org + px;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + c0 + part * 8);
+            *reinterpret_cast<uint4*>(patch + (size_t)pix * LT_PIXB + part * 16) = v;
+        }
+        for (int i = tid; i < 16 * MT * taps * 4; i += 256) {
+            const int row = i / (taps * 4), rem = i - row * taps * 4, tap = rem >> 2, part = rem & 3;
+            *reinterpret_cast<uint4*>(wts + (size_t)row * wrowb + (tap * LT_CK + part * 8) * 2) =
+                *reinterpret_cast<const uint4*>(a.wgt + (size_t)(ch_base + row) * a.kpad + tap * a.cin + c0 + part * 8);
+        }
+        __syncthreads();
+        for (int tap = 0; tap < taps; ++tap) {
+            const int ky = a.ksz == 1 ? 0 : tap / 3, kx = a.ksz == 1 ? 0 : tap - ky * 3;
+            bf16x8 A[MT], B[2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                A[mt] = *reinterpret_cast<const bf16x8*>(wts + (size_t)(mt * 16 + l15) * wrowb + (tap * LT_CK + 8 * h) * 2);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                B[nt] = *reinterpret_cast<const bf16x8*>(patch + (size_t)(((2 * wave + nt) * s + ky) * PW + l15 * s + kx) * LT_PIXB + 16 * h);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch = ch_base + mt * 16 + 4 * h;
+        const float4 bs = *reinterpret_cast<const float4*>(a.bias + ch);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int oy = oy0 + 2 * wave + nt, ox = ox0 + l15;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t p = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+            float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
+            if (a.act)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.0f + __expf(-v[q]));
             if (a.res) {
                 const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
                 v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
@@ -519,6 +607,11 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         av_set_error("av_yolo_create: graph construction failed (parameter blob / capacity mismatch)");
         return AV_EINVAL;
     }
+    // stride-2 3x3 tiles need 45 KB of patch + up to 47 KB of weights
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     // the NMS kernel keeps all sorted boxes in LDS (16 B each): above the default 64 KB dynamic limit
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)((size_t)y.A * 16 + (size_t)((y.A + 31) / 32) * 4 + 16)));
@@ -568,6 +661,19 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     for (const Yolo::Op& op : y.ops) {
         if (op.kind == 0) {
             const ConvArgs& a = op.ca;
+            if (a.cin % LT_CK == 0 && a.stride == 1 && !getenv("AVHOT_CONV_DIRECT")) {
+                const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
+                const int taps = a.ksz * a.ksz;
+                const int PH = (LT_H - 1) * a.stride + a.ksz, PW = (LT_W - 1) * a.stride + a.ksz;
+                const size_t lds = (((size_t)PH * PW * LT_PIXB + 15) & ~size_t(15)) + (size_t)16 * op.mt * (taps * LT_CK * 2 + 16);
+                const dim3 lgrid(tiles_x * tiles_y * B, a.cout / (16 * op.mt));
+                if (op.mt == 4) hipLaunchKernelGGL((conv_lds_kernel<4>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
+                else if (op.mt == 5) hipLaunchKernelGGL((conv_lds_kernel<5>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
+                else if (op.mt == 2) hipLaunchKernelGGL((conv_lds_kernel<2>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
+                else hipLaunchKernelGGL((conv_lds_kernel<1>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
+                AV_LAUNCH_CHECK();
+                continue;
+            }
             constexpr int NT = 2;
             const dim3 grid((a.npix + 16 * NT * 4 - 1) / (16 * NT * 4), a.cout / (16 * op.mt));
             if (op.mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, NT>), grid, dim3(256), 0, st, a);
