@@ -97,7 +97,8 @@ __device__ __forceinline__ double dpp_mov_keep_f64(double v) {
     const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
     return __hiloint2double(nhi, nlo);
 }
-__device__ __forceinline__ double fmax_nn(double a, double b) { return b > a ? b : a; }
+// v_max_f64; operands are never NaN here, so this is the plain maximum
+__device__ __forceinline__ double fmax_nn(double a, double b) { return __builtin_fmax(a, b); }
 // Wave-wide maximum (no NaNs expected), result uniform in every lane.
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax_nn(v, dpp_mov_keep_f64<0xB1>(v));
@@ -107,6 +108,33 @@ __device__ __forceinline__ double wave_max(double v) {
     v = fmax_nn(v, dpp_mov_keep_f64<0x142, 0xA>(v));
     v = fmax_nn(v, dpp_mov_keep_f64<0x143, 0xC>(v));
     return readlane_f64(v, 63);
+}
+// Unsigned 32-bit wave maximum: one VOP2 with a DPP operand per step.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    // old = 0 is the identity of an unsigned max (also for the lanes a partial row mask leaves unwritten),
+    // which lets the DPP operand fold into v_max_u32_dpp
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_max_u32<0xB1>(v);
+    v = dpp_max_u32<0x4E>(v);
+    v = dpp_max_u32<0x141>(v);
+    v = dpp_max_u32<0x140>(v);
+    v = dpp_max_u32<0x142, 0xA>(v);
+    v = dpp_max_u32<0x143, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Lanes holding the maximum of v over the `valid` lanes, v >= +0.0 there (never NaN): non-negative
+// doubles order like their (hi, lo) words as unsigned integers, so two u32 reductions replace the
+// f64 compare/select chain.  Returns 0 when no lane is valid.
+__device__ __forceinline__ unsigned long long wave_argmax_nonneg(double v, bool valid) {
+    const unsigned hi = valid ? (unsigned)__double2hiint(v) : 0u, lo = (unsigned)__double2loint(v);
+    const unsigned mh = wave_max_u32(hi);
+    const bool top = valid && hi == mh;
+    const unsigned ml = wave_max_u32(top ? lo : 0u);
+    return __ballot(top && lo == ml);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll

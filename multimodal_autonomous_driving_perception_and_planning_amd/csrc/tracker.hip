@@ -98,13 +98,14 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Shared& sh = *reinterpret_cast<Shared*>(smem);
     av_track_row* stage = reinterpret_cast<av_track_row*>(smem + ((sizeof(Shared) + 63) & ~size_t(63)));
-    // detections of a chunk of FC frames: n[FC] | box[FC][dcap][4] | cls[FC][dcap] | conf[FC][dcap]
+    // detections of a chunk of FC frames: n[FC] | box[FC][dcap][4] | cls[FC][dcap] | conf[FC][dcap] | area[FC][dcap]
     unsigned char* chunk = reinterpret_cast<unsigned char*>(stage + tcap);
     const int FC = chunk_frames;
     int* c_n = reinterpret_cast<int*>(chunk);
     int* c_box = c_n + ((FC + 3) & ~3);
     int* c_cls = c_box + (size_t)FC * dcap * 4;
     double* c_conf = reinterpret_cast<double*>(c_cls + (((size_t)FC * dcap + 1) & ~size_t(1)));
+    double* c_area = c_conf + (size_t)FC * dcap;       // (x2-x1)*(y2-y1) of every staged detection, exact in f64
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -143,7 +144,11 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
             lds_sync<MULTIWAVE>();
             for (int i = tid; i < nfr; i += blockDim.x) c_n[i] = det_n[sf + i];
             const int4* gb = reinterpret_cast<const int4*>(det_box) + sf * dcap;
-            for (int i = tid; i < nfr * dcap; i += blockDim.x) reinterpret_cast<int4*>(c_box)[i] = gb[i];
+            for (int i = tid; i < nfr * dcap; i += blockDim.x) {
+                const int4 b = gb[i];
+                reinterpret_cast<int4*>(c_box)[i] = b;
+                c_area[i] = (double)(b.z - b.x) * (double)(b.w - b.y);
+            }
             for (int i = tid; i < nfr * dcap; i += blockDim.x) {
                 c_cls[i] = det_cls[sf * dcap + i];
                 c_conf[i] = det_conf[sf * dcap + i];
@@ -156,6 +161,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         const int* dbox = c_box + (size_t)fl * dcap * 4;        // [dcap][4]
         const int* dcls = c_cls + (size_t)fl * dcap;
         const double* dconf = c_conf + (size_t)fl * dcap;
+        const double* darea = c_area + (size_t)fl * dcap;
         frame_count += 1;
         if (tid < dcap) sh.d2t[tid] = -1;
         lds_sync<MULTIWAVE>();
@@ -167,7 +173,90 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         double best = -1.0;
         int best_j = -1;
         double ious[DREG > 0 ? DREG : 1];
-        if (DREG > 0) {
+        bool need_loop = true;                // run the generic greedy arg-max loop below
+        if (DREG > 0 && !MULTIWAVE && cfg.iou_threshold > 0.0) {
+            // ---- divide-free front end ---------------------------------------------------------------
+            // (1) candidate test: v = fl(inter/uni) >= thr is decided by comparing inter with thr*uni
+            //     outside the band thr*(1 +- 2^-40)*uni (the quotient is then further from thr than any
+            //     rounding can move it); only columns with a lane inside that band pay for the divide.
+            // (2) an edge whose row and column hold no other candidate is taken by the greedy loop
+            //     whatever the order -> matched at once.
+            // (3) the remaining ("contested") columns get exact quotients; when none of their rows has
+            //     a second candidate the columns are independent and each one's winner is its arg-max
+            //     (lowest row on ties == first in row-major order, :150).  Anything else falls through
+            //     to the generic loop with the isolated matches already entered.
+            constexpr int DR = DREG > 0 ? DREG : 1;
+            const double thr = cfg.iou_threshold;
+            const double thr_hi = thr * (1.0 + 0x1p-40), thr_lo = thr * (1.0 - 0x1p-40);
+            double inter[DR], uni[DR];
+            unsigned long long m[DR];
+            unsigned cm = 0, have_exact = 0;
+            const double a1 = (double)(r.x2 - r.x1) * (double)(r.y2 - r.y1);
+#pragma unroll
+            for (int j = 0; j < DR; ++j) {
+                m[j] = 0;
+                ious[j] = -1.0;
+                inter[j] = 0.0, uni[j] = 1.0;
+                if (j < nd) {                                   // uniform: nd is the frame's detection count
+                    const int4 b = *reinterpret_cast<const int4*>(dbox + j * 4);
+                    const int xi1 = r.x1 > b.x ? r.x1 : b.x, yi1 = r.y1 > b.y ? r.y1 : b.y;
+                    const int xi2 = r.x2 < b.z ? r.x2 : b.z, yi2 = r.y2 < b.w ? r.y2 : b.w;
+                    const int iw = xi2 - xi1, ih = yi2 - yi1;
+                    inter[j] = (double)iw * (double)ih;
+                    uni[j] = a1 + darea[j] - inter[j];
+                    // iw, ih > 0 implies both areas > 0 and uni >= max(a1, a2) > 0 (:95-105)
+                    const bool valid = active && iw > 0 && ih > 0;
+                    bool c = valid && inter[j] >= thr_hi * uni[j];
+                    if (__ballot(valid && !c && inter[j] >= thr_lo * uni[j])) {   // uniform, rare: too close to call
+                        const double v = valid ? inter[j] / uni[j] : 0.0;
+                        c = valid && v >= thr;                       // :147
+                        ious[j] = c ? v : -1.0;
+                        have_exact |= 1u << j;
+                    }
+                    m[j] = __ballot(c);
+                    cm |= c ? (1u << j) : 0u;
+                }
+            }
+            const unsigned long long rowmulti = __ballot(__popc(cm) >= 2);
+            unsigned iso = 0, cc = 0;
+            unsigned long long crow = 0;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) {
+                if (m[j]) {
+                    if (__popcll(m[j]) >= 2 || (m[j] & rowmulti)) cc |= 1u << j, crow |= m[j];
+                    else iso |= 1u << j;
+                }
+            }
+            used = iso;
+            if (cm & iso) matched_j = __ffs((int)(cm & iso)) - 1;
+            need_loop = false;
+            if (cc) {
+#pragma unroll
+                for (int j = 0; j < DR; ++j) {
+                    if ((cc >> j) & 1u) {
+                        if (!((have_exact >> j) & 1u)) {
+                            const bool c = (cm >> j) & 1u;
+                            const double v = c ? inter[j] / uni[j] : 0.0;
+                            ious[j] = c ? v : -1.0;
+                        }
+                    } else {
+                        ious[j] = -1.0;
+                    }
+                }
+                if ((crow & rowmulti) == 0ull) {
+#pragma unroll
+                    for (int j = 0; j < DR; ++j) {
+                        if ((cc >> j) & 1u) {
+                            const unsigned long long bal = wave_argmax_nonneg(ious[j], ious[j] >= 0.0);
+                            if (lane == __ffsll((long long)bal) - 1) matched_j = j;
+                        }
+                    }
+                    used |= cc;
+                } else {
+                    need_loop = true;
+                }
+            }
+        } else if (DREG > 0) {
             // all detection boxes of the frame in one batch of LDS reads (uniform addresses), then a
             // branch-free IoU pass: slots >= nd and rows >= T get -1
             int4 db[DREG > 0 ? DREG : 1];
@@ -207,13 +296,19 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
             }
             if (!(best >= cfg.iou_threshold)) best = -1.0, best_j = -1;   // :147  max < thr -> stop
         };
-        if (active && nd > 0) recompute();
-        if (T > 0 && nd > 0) {
+        if (need_loop && active && matched_j < 0 && nd > 0) recompute();
+        if (need_loop && T > 0 && nd > 0) {
             const int max_iter = T < nd ? T : nd;
             for (int it = 0; it < max_iter; ++it) {
                 const double key = (active && matched_j < 0 && best_j >= 0) ? best : -1.0;
-                const double wmax = wave_max(key);
-                const unsigned long long bal = __ballot(key == wmax && key >= 0.0);
+                double wmax = -1.0;
+                unsigned long long bal;
+                if (MULTIWAVE) {
+                    wmax = wave_max(key);
+                    bal = __ballot(key == wmax && key >= 0.0);
+                } else {
+                    bal = wave_argmax_nonneg(key, key >= 0.0);
+                }
                 int win_row = -1, win_col = -1;
                 double win_iou = -1.0;
                 if (bal) {
@@ -408,12 +503,12 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
                "av_tracker_update: iou_threshold < 0 never terminates in the reference either");
     AV_REQUIRE((snap == nullptr) == (snap_n == nullptr), AV_EINVAL, "av_tracker_update: snap and snap_n go together");
     // chunk of frames whose detections are staged in LDS at once (~16 KB)
-    const size_t per_frame = 4 + (size_t)dcap * (16 + 4 + 8);
+    const size_t per_frame = 4 + (size_t)dcap * (16 + 4 + 8 + 8);
     int fc = (int)(16384 / per_frame);
     fc = fc < 1 ? 1 : (fc > 64 ? 64 : fc);
     if (fc > n_frames) fc = n_frames;
     const size_t chunk_bytes = (size_t)((fc + 3) & ~3) * 4 + (size_t)fc * dcap * 16 + (((size_t)fc * dcap + 1) & ~size_t(1)) * 4 +
-                               (size_t)fc * dcap * 8 + 16;
+                               (size_t)fc * dcap * 16 + 16;
     const size_t lds = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row) + chunk_bytes;
 #define AV_TRK_LAUNCH(MW, DR)                                                                                     \
     hipLaunchKernelGGL((tracker_kernel<MW, DR>), dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,  \
