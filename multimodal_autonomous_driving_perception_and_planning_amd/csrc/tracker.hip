@@ -13,6 +13,12 @@
 // its best unused detection (lowest column on ties) and recomputes it only when that column is
 // taken, which reproduces the reference's pick order exactly.  The float64 quotient inter/union is
 // formed from exact integers, so every comparison sees the bits NumPy sees.
+//
+// REP > 1 (tcap 64, dcap <= REP): the per-frame work of ONE stream is a latency chain a single wave cannot
+// hide, so REP waves each hold the same table (lane == row) and split the association by detection
+// column: wave w tests column w against every row and resolves that column's contest, the results
+// cross through LDS with one barrier per frame, and every wave then applies the identical update to its
+// own copy (private LDS scratch, no further communication).  Global writes are shared out by wave.
 #include "common.h"
 
 namespace {
@@ -89,27 +95,38 @@ __device__ __forceinline__ void lds_sync() {
 
 // DREG > 0: the row's IoU against every detection (dcap <= DREG) is computed once per frame and kept in
 // registers; DREG == 0: generic path for larger dcap (best candidate recomputed when its column is taken).
-template <bool MULTIWAVE, int DREG>
-__global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
+template <bool MULTIWAVE, int DREG, int REP>
+__global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
                                const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
                                int32_t* __restrict__ det2trk, int chunk_frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Shared& sh = *reinterpret_cast<Shared*>(smem);
-    av_track_row* stage = reinterpret_cast<av_track_row*>(smem + ((sizeof(Shared) + 63) & ~size_t(63)));
+    constexpr bool REPL = REP > 1;
+    static_assert(!(REPL && MULTIWAVE), "replica waves hold the whole table: tcap must be 64");
+    static_assert(REP == 1 || REP == 8, "the exchange buffers are laid out for 8 columns");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int row = REPL ? lane : tid;                 // table row this thread holds
+    // per replica: Shared | stage[tcap];  then the detection chunk;  then (REPL) the exchange buffers
+    const size_t sh_bytes = (sizeof(Shared) + 63) & ~size_t(63);
+    const size_t rep_bytes = sh_bytes + (size_t)tcap * sizeof(av_track_row);
+    unsigned char* rbase = smem + (REPL ? (size_t)wid * rep_bytes : 0);
+    Shared& sh = *reinterpret_cast<Shared*>(rbase);
+    av_track_row* stage = reinterpret_cast<av_track_row*>(rbase + sh_bytes);
     // detections of a chunk of FC frames: n[FC] | box[FC][dcap][4] | cls[FC][dcap] | conf[FC][dcap] | area[FC][dcap]
-    unsigned char* chunk = reinterpret_cast<unsigned char*>(stage + tcap);
+    unsigned char* chunk = smem + (size_t)REP * rep_bytes;
     const int FC = chunk_frames;
     int* c_n = reinterpret_cast<int*>(chunk);
     int* c_box = c_n + ((FC + 3) & ~3);
     int* c_cls = c_box + (size_t)FC * dcap * 4;
     double* c_conf = reinterpret_cast<double*>(c_cls + (((size_t)FC * dcap + 1) & ~size_t(1)));
     double* c_area = c_conf + (size_t)FC * dcap;       // (x2-x1)*(y2-y1) of every staged detection, exact in f64
+    // exchange, one buffer per frame parity: cand[64 rows][8 cols] bytes | count[8] | any[8] | winner[8]
+    constexpr int XB = 576;
+    unsigned char* xchg = reinterpret_cast<unsigned char*>(c_area + (size_t)FC * dcap);
 
     const int s = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
     const int nwaves = (tcap + 63) >> 6;
     const int L = cfg.trajectory_length;
 
@@ -120,8 +137,8 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
 
     int T = hdr[0], next_id = hdr[1], frame_count = hdr[2], status = hdr[3];
     Row r{};
-    if (tid < T) {
-        const av_track_row g = rows[tid];
+    if (row < T) {
+        const av_track_row g = rows[row];
         r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
         r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
         r.conf = g.conf;
@@ -130,9 +147,9 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
     // the frame loop, where (vmcnt counts loads and stores in order) it would also drain the previous
     // frame's output stores on every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt/lgkmcnt untouched
-    if (tid < 32) sh.slot_bits[tid] = 0;
+    if (row < 32) sh.slot_bits[row] = 0;
     lds_sync<MULTIWAVE>();
-    if (tid < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
+    if (row < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
     lds_sync<MULTIWAVE>();
 
     for (int f = 0; f < n_frames; ++f) {
@@ -141,7 +158,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         if (fl == 0) {
             // one cooperative load of the next FC frames' detections; the only global reads of the loop
             const int nfr = (n_frames - f) < FC ? (n_frames - f) : FC;
-            lds_sync<MULTIWAVE>();
+            lds_sync<MULTIWAVE || REPL>();
             for (int i = tid; i < nfr; i += blockDim.x) c_n[i] = det_n[sf + i];
             const int4* gb = reinterpret_cast<const int4*>(det_box) + sf * dcap;
             for (int i = tid; i < nfr * dcap; i += blockDim.x) {
@@ -154,7 +171,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 c_conf[i] = det_conf[sf * dcap + i];
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            lds_sync<MULTIWAVE>();
+            lds_sync<MULTIWAVE || REPL>();
         }
         int nd = c_n[fl];
         nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
@@ -163,100 +180,140 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         const double* dconf = c_conf + (size_t)fl * dcap;
         const double* darea = c_area + (size_t)fl * dcap;
         frame_count += 1;
-        if (tid < dcap) sh.d2t[tid] = -1;
+        if (row < dcap) sh.d2t[row] = -1;
         lds_sync<MULTIWAVE>();
 
         // ---- association (multi_object_tracker.py:113-164) ------------------------------------
         unsigned long long used = 0;          // columns already taken; identical in every thread
         int matched_j = -1;
-        const bool active = tid < T;
+        const bool active = row < T;
         double best = -1.0;
         int best_j = -1;
         double ious[DREG > 0 ? DREG : 1];
-        bool need_loop = true;                // run the generic greedy arg-max loop below
-        if (DREG > 0 && !MULTIWAVE && cfg.iou_threshold > 0.0) {
+        bool need_loop = true;                // run the all-pairs IoU pass + generic greedy arg-max loop below
+        if (REPL) {
+            // ---- replica waves: wave w owns detection column w --------------------------------------------
+            // Same three facts as the single-wave front end below (guard-banded threshold test; with no row
+            // holding two candidates the columns are independent; a contested column's winner is its arg-max),
+            // with the columns spread over the waves.  Published per column: the candidate bit of every row,
+            // the candidate count and the winning row.  After the barrier each wave rebuilds its rows'
+            // candidate sets; if some row has two candidates all waves take the generic path (identically).
+            const double thr = cfg.iou_threshold;
+            const double thr_hi = thr * (1.0 + 0x1p-40), thr_lo = thr * (1.0 - 0x1p-40);
+            unsigned char* xb = xchg + (f & 1) * XB;
+            bool c = false;
+            int pc = 0, winner = 255;
+            if (wid < nd) {
+                const int j = wid;
+                const int4 b = *reinterpret_cast<const int4*>(dbox + j * 4);
+                const int xi1 = r.x1 > b.x ? r.x1 : b.x, yi1 = r.y1 > b.y ? r.y1 : b.y;
+                const int xi2 = r.x2 < b.z ? r.x2 : b.z, yi2 = r.y2 < b.w ? r.y2 : b.w;
+                const int iw = xi2 - xi1, ih = yi2 - yi1;
+                const double a1 = (double)(r.x2 - r.x1) * (double)(r.y2 - r.y1);
+                const double inter = (double)iw * (double)ih;
+                const double uni = a1 + darea[j] - inter;
+                const bool valid = active && iw > 0 && ih > 0;      // then uni >= max(a1, a2) > 0 (:95-105)
+                c = valid && inter >= thr_hi * uni;
+                double v = 0.0;
+                bool have_v = false;
+                if (__ballot(valid && !c && inter >= thr_lo * uni)) {     // uniform, rare: too close to call
+                    v = valid ? inter / uni : 0.0;
+                    c = valid && v >= thr;                                   // :147
+                    have_v = true;
+                }
+                const unsigned long long m = __ballot(c);
+                pc = __popcll(m);
+                if (pc == 1) {
+                    winner = __ffsll((long long)m) - 1;
+                } else if (pc >= 2) {
+                    if (!have_v) v = c ? inter / uni : 0.0;                  // the reference's float64 divide (:105)
+                    winner = __ffsll((long long)wave_argmax_nonneg(v, c)) - 1;
+                }
+            }
+            xb[lane * 8 + wid] = c ? (unsigned char)(1u << wid) : (unsigned char)0;
+            if (lane == 0) {
+                xb[512 + wid] = (unsigned char)(pc ? (1u << wid) : 0u);
+                xb[520 + wid] = (unsigned char)winner;
+            }
+            lds_sync<true>();
+            auto orfold = [](unsigned long long x) {
+                unsigned t = (unsigned)x | (unsigned)(x >> 32);
+                t |= t >> 16;
+                t |= t >> 8;
+                return t & 0xFFu;
+            };
+            const unsigned cm = orfold(*reinterpret_cast<const unsigned long long*>(xb + lane * 8));
+            const unsigned long long anys = *reinterpret_cast<const unsigned long long*>(xb + 512);
+            const unsigned long long wins = *reinterpret_cast<const unsigned long long*>(xb + 520);
+            if (__ballot(__popc(cm) >= 2) == 0ull) {
+                need_loop = false;
+                used = (unsigned long long)__builtin_amdgcn_readfirstlane((int)orfold(anys));
+                const bool has = cm != 0u;
+                const int my_col = has ? __ffs((int)cm) - 1 : 0;
+                if (has && (int)((wins >> (8 * my_col)) & 0xFFull) == lane) matched_j = my_col;
+            }
+        } else if (DREG > 0 && !MULTIWAVE && cfg.iou_threshold > 0.0) {
             // ---- divide-free front end ---------------------------------------------------------------
             // (1) candidate test: v = fl(inter/uni) >= thr is decided by comparing inter with thr*uni
             //     outside the band thr*(1 +- 2^-40)*uni (the quotient is then further from thr than any
             //     rounding can move it); only columns with a lane inside that band pay for the divide.
-            // (2) an edge whose row and column hold no other candidate is taken by the greedy loop
-            //     whatever the order -> matched at once.
-            // (3) the remaining ("contested") columns get exact quotients; when none of their rows has
-            //     a second candidate the columns are independent and each one's winner is its arg-max
-            //     (lowest row on ties == first in row-major order, :150).  Anything else falls through
-            //     to the generic loop with the isolated matches already entered.
-            constexpr int DR = DREG > 0 ? DREG : 1;
+            // (2) while no row holds two candidates a row carries ONE edge (its column, inter, uni), and
+            //     a row taken by the greedy loop removes nothing from any other column: the columns are
+            //     independent, each one's winner is its arg-max (lowest row on ties == first in row-major
+            //     order, :150), and a column with a single candidate needs no quotient at all.
+            // (3) the contested columns share one exact divide and are resolved by a u32 DPP arg-max each.
+            // A frame in which some row has two candidates takes the generic path below instead.
             const double thr = cfg.iou_threshold;
             const double thr_hi = thr * (1.0 + 0x1p-40), thr_lo = thr * (1.0 - 0x1p-40);
-            double inter[DR], uni[DR];
-            unsigned long long m[DR];
-            unsigned cm = 0, have_exact = 0;
             const double a1 = (double)(r.x2 - r.x1) * (double)(r.y2 - r.y1);
-#pragma unroll
-            for (int j = 0; j < DR; ++j) {
-                m[j] = 0;
-                ious[j] = -1.0;
-                inter[j] = 0.0, uni[j] = 1.0;
-                if (j < nd) {                                   // uniform: nd is the frame's detection count
-                    const int4 b = *reinterpret_cast<const int4*>(dbox + j * 4);
-                    const int xi1 = r.x1 > b.x ? r.x1 : b.x, yi1 = r.y1 > b.y ? r.y1 : b.y;
-                    const int xi2 = r.x2 < b.z ? r.x2 : b.z, yi2 = r.y2 < b.w ? r.y2 : b.w;
-                    const int iw = xi2 - xi1, ih = yi2 - yi1;
-                    inter[j] = (double)iw * (double)ih;
-                    uni[j] = a1 + darea[j] - inter[j];
-                    // iw, ih > 0 implies both areas > 0 and uni >= max(a1, a2) > 0 (:95-105)
-                    const bool valid = active && iw > 0 && ih > 0;
-                    bool c = valid && inter[j] >= thr_hi * uni[j];
-                    if (__ballot(valid && !c && inter[j] >= thr_lo * uni[j])) {   // uniform, rare: too close to call
-                        const double v = valid ? inter[j] / uni[j] : 0.0;
-                        c = valid && v >= thr;                       // :147
-                        ious[j] = c ? v : -1.0;
-                        have_exact |= 1u << j;
-                    }
-                    m[j] = __ballot(c);
-                    cm |= c ? (1u << j) : 0u;
+            int cnt = 0, my_col = 0;
+            double s_inter = 0.0, s_uni = 1.0;
+            unsigned long long colcnt4 = 0;                       // per column: candidate count, 4 bits, saturating
+            unsigned anyc = 0;                                    // columns with any candidate
+#pragma unroll 1
+            for (int j = 0; j < nd; ++j) {
+                const int4 b = *reinterpret_cast<const int4*>(dbox + j * 4);
+                const int xi1 = r.x1 > b.x ? r.x1 : b.x, yi1 = r.y1 > b.y ? r.y1 : b.y;
+                const int xi2 = r.x2 < b.z ? r.x2 : b.z, yi2 = r.y2 < b.w ? r.y2 : b.w;
+                const int iw = xi2 - xi1, ih = yi2 - yi1;
+                const double inter = (double)iw * (double)ih;
+                const double uni = a1 + darea[j] - inter;
+                // iw, ih > 0 implies both areas > 0 and uni >= max(a1, a2) > 0 (:95-105)
+                const bool valid = active && iw > 0 && ih > 0;
+                bool c = valid && inter >= thr_hi * uni;
+                if (__ballot(valid && !c && inter >= thr_lo * uni)) {     // uniform, rare: too close to call
+                    const double v = valid ? inter / uni : 0.0;
+                    c = valid && v >= thr;                                   // :147
                 }
+                const int pc = __popcll(__ballot(c));
+                colcnt4 |= (unsigned long long)(pc > 15 ? 15 : pc) << (4 * j);
+                anyc |= (pc ? 1u : 0u) << j;
+                cnt += c ? 1 : 0;
+                my_col = c ? j : my_col;
+                s_inter = c ? inter : s_inter;
+                s_uni = c ? uni : s_uni;
             }
-            const unsigned long long rowmulti = __ballot(__popc(cm) >= 2);
-            unsigned iso = 0, cc = 0;
-            unsigned long long crow = 0;
-#pragma unroll
-            for (int j = 0; j < DR; ++j) {
-                if (m[j]) {
-                    if (__popcll(m[j]) >= 2 || (m[j] & rowmulti)) cc |= 1u << j, crow |= m[j];
-                    else iso |= 1u << j;
-                }
-            }
-            used = iso;
-            if (cm & iso) matched_j = __ffs((int)(cm & iso)) - 1;
-            need_loop = false;
-            if (cc) {
-#pragma unroll
-                for (int j = 0; j < DR; ++j) {
-                    if ((cc >> j) & 1u) {
-                        if (!((have_exact >> j) & 1u)) {
-                            const bool c = (cm >> j) & 1u;
-                            const double v = c ? inter[j] / uni[j] : 0.0;
-                            ious[j] = c ? v : -1.0;
-                        }
-                    } else {
-                        ious[j] = -1.0;
+            if (__ballot(cnt >= 2) == 0ull) {
+                need_loop = false;
+                used = anyc;                                          // every column with a candidate gets matched
+                const int mycnt = (int)((colcnt4 >> (4 * my_col)) & 15ull);
+                const bool has = cnt == 1;
+                if (has && mycnt == 1) matched_j = my_col;
+                const bool fights = has && mycnt >= 2;
+                unsigned long long rem = __ballot(fights);
+                if (rem) {
+                    const double v = fights ? s_inter / s_uni : 0.0;  // the reference's one float64 divide (:105)
+                    while (rem) {
+                        const int j = __builtin_amdgcn_readlane(my_col, __ffsll((long long)rem) - 1);
+                        const bool in = fights && my_col == j;
+                        const unsigned long long bal = wave_argmax_nonneg(v, in);
+                        if (lane == __ffsll((long long)bal) - 1) matched_j = j;
+                        rem &= ~__ballot(in);
                     }
                 }
-                if ((crow & rowmulti) == 0ull) {
-#pragma unroll
-                    for (int j = 0; j < DR; ++j) {
-                        if ((cc >> j) & 1u) {
-                            const unsigned long long bal = wave_argmax_nonneg(ious[j], ious[j] >= 0.0);
-                            if (lane == __ffsll((long long)bal) - 1) matched_j = j;
-                        }
-                    }
-                    used |= cc;
-                } else {
-                    need_loop = true;
-                }
             }
-        } else if (DREG > 0) {
+        }
+        if (need_loop && DREG > 0) {
             // all detection boxes of the frame in one batch of LDS reads (uniform addresses), then a
             // branch-free IoU pass: slots >= nd and rows >= T get -1
             int4 db[DREG > 0 ? DREG : 1];
@@ -313,7 +370,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 double win_iou = -1.0;
                 if (bal) {
                     const int leader = __ffsll((long long)bal) - 1;
-                    win_row = (wid << 6) + leader;
+                    win_row = (REPL ? 0 : (wid << 6)) + leader;
                     win_col = __shfl(best_j, leader, 64);
                     win_iou = wmax;
                 }
@@ -327,7 +384,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 }
                 if (win_row < 0) break;
                 used |= 1ull << win_col;
-                if (tid == win_row) matched_j = win_col;
+                if (row == win_row) matched_j = win_col;
                 else if (active && matched_j < 0 && best_j == win_col) recompute();
             }
         }
@@ -343,7 +400,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 r.conf = dconf[matched_j];
                 r.age += 1, r.hits += 1, r.misses = 0;
                 double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + (r.hlen % L)) * 4);
-                *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                if (!REPL || wid == 0) *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
                 r.hlen += 1;
                 sh.d2t[matched_j] = r.id;
             } else {
@@ -360,19 +417,19 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         if (nb > 0) {
             // rank of each free history slot; the b-th birth takes the b-th free slot
             {
-                const unsigned word = sh.slot_bits[tid >> 5];
-                const bool is_free = !((word >> (tid & 31)) & 1u);
-                int below = __popc(~word & ((1u << (tid & 31)) - 1u));
-                for (int w = 0; w < (tid >> 5); ++w) below += 32 - __popc(sh.slot_bits[w]);
-                if (is_free && below < nb_fit) sh.birth_slot[below] = tid;
+                const unsigned word = sh.slot_bits[row >> 5];
+                const bool is_free = !((word >> (row & 31)) & 1u);
+                int below = __popc(~word & ((1u << (row & 31)) - 1u));
+                for (int w = 0; w < (row >> 5); ++w) below += 32 - __popc(sh.slot_bits[w]);
+                if (is_free && below < nb_fit) sh.birth_slot[below] = row;
             }
-            if (tid < nd && ((unm >> tid) & 1ull)) {
-                const int b = __popcll(unm & ((1ull << tid) - 1ull));
-                sh.d2t[tid] = next_id + b;
+            if (row < nd && ((unm >> row) & 1ull)) {
+                const int b = __popcll(unm & ((1ull << row) - 1ull));
+                sh.d2t[row] = next_id + b;
             }
             lds_sync<MULTIWAVE>();
-            if (tid >= T && tid < T + nb_fit) {
-                const int b = tid - T;
+            if (row >= T && row < T + nb_fit) {
+                const int b = row - T;
                 const int j = nth_set_bit(unm, b);
                 r.id = next_id + b;
                 r.x1 = dbox[j * 4 + 0], r.y1 = dbox[j * 4 + 1], r.x2 = dbox[j * 4 + 2], r.y2 = dbox[j * 4 + 3];
@@ -382,7 +439,7 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
                 r.slot = sh.birth_slot[b];
                 r.hlen = 1;
                 double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
-                *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
+                if (!REPL || wid == 0) *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
                 atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
             }
             next_id += nb;
@@ -390,11 +447,11 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         }
 
         // ---- deaths (:228-233): order-preserving compaction --------------------------------------
-        const bool live_row = tid < T;
+        const bool live_row = row < T;
         const bool dead = live_row && (r.misses > cfg.max_age);
         int any_dead;
         if (MULTIWAVE) {
-            if (tid == 0) sh.misc[0] = 0;
+            if (row == 0) sh.misc[0] = 0;
             lds_sync<MULTIWAVE>();
             if (dead) sh.misc[0] = 1;
             lds_sync<MULTIWAVE>();
@@ -426,8 +483,8 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
             }
             lds_sync<MULTIWAVE>();
             T = total;
-            if (tid < T) {
-                const av_track_row g = stage[tid];
+            if (row < T) {
+                const av_track_row g = stage[row];
                 r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
                 r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
                 r.conf = g.conf;
@@ -435,31 +492,32 @@ __global__ void tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const
         }
 
         // ---- per-frame outputs --------------------------------------------------------------------
-        if (snap) {
-            if (tid < T) {
+        if (snap && (!REPL || wid == 1)) {
+            if (row < T) {
                 av_track_row g;
                 g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
                 g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
                 g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
                 g.conf = r.conf, g.reserved = 0.0;
-                snap[sf * tcap + tid] = g;
+                snap[sf * tcap + row] = g;
             }
-            if (tid == 0) snap_n[sf] = T;
+            if (row == 0) snap_n[sf] = T;
         }
-        if (det2trk && tid < dcap) det2trk[sf * dcap + tid] = sh.d2t[tid];
+        if (det2trk && row < dcap && (!REPL || wid == 2)) det2trk[sf * dcap + row] = sh.d2t[row];
         lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
     }
 
     // ---- persist ----------------------------------------------------------------------------------
-    if (tid < T) {
+    if (REPL && wid != 0) return;
+    if (row < T) {
         av_track_row g;
         g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
         g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
         g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
         g.conf = r.conf, g.reserved = 0.0;
-        rows[tid] = g;
+        rows[row] = g;
     }
-    if (tid == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
+    if (row == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
 }
 
 __global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, unsigned char* state) {
@@ -509,17 +567,25 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
     if (fc > n_frames) fc = n_frames;
     const size_t chunk_bytes = (size_t)((fc + 3) & ~3) * 4 + (size_t)fc * dcap * 16 + (((size_t)fc * dcap + 1) & ~size_t(1)) * 4 +
                                (size_t)fc * dcap * 16 + 16;
-    const size_t lds = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row) + chunk_bytes;
-#define AV_TRK_LAUNCH(MW, DR)                                                                                     \
-    hipLaunchKernelGGL((tracker_kernel<MW, DR>), dim3(n_streams), dim3(tcap), lds, as_stream(stream), *cfg, n_frames,  \
-                       dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk, fc)
-    if (tcap == 64) {
-        if (dcap <= 8) AV_TRK_LAUNCH(false, 8);
-        else if (dcap <= 16) AV_TRK_LAUNCH(false, 16);
-        else AV_TRK_LAUNCH(false, 0);
+    // replica waves (one per detection column) for the common table size; AVHOT_TRACKER_REP=1 keeps one wave
+    constexpr int REPW = 8;
+    const char* rep_env = getenv("AVHOT_TRACKER_REP");
+    const bool rep = tcap == 64 && dcap <= REPW && cfg->iou_threshold > 0.0 && !(rep_env && atoi(rep_env) <= 1);
+    const size_t rep_bytes = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
+    const size_t lds = rep_bytes * (rep ? REPW : 1) + chunk_bytes + (rep ? 2 * 576 : 0);
+#define AV_TRK_LAUNCH(MW, DR, RP)                                                                                  \
+    hipLaunchKernelGGL((tracker_kernel<MW, DR, RP>), dim3(n_streams), dim3(tcap * RP), lds, as_stream(stream), *cfg,   \
+                       n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, \
+                       det2trk, fc)
+    if (rep) {
+        AV_TRK_LAUNCH(false, 8, REPW);
+    } else if (tcap == 64) {
+        if (dcap <= 8) AV_TRK_LAUNCH(false, 8, 1);
+        else if (dcap <= 16) AV_TRK_LAUNCH(false, 16, 1);
+        else AV_TRK_LAUNCH(false, 0, 1);
     } else {
-        if (dcap <= 8) AV_TRK_LAUNCH(true, 8);
-        else AV_TRK_LAUNCH(true, 0);
+        if (dcap <= 8) AV_TRK_LAUNCH(true, 8, 1);
+        else AV_TRK_LAUNCH(true, 0, 1);
     }
 #undef AV_TRK_LAUNCH
     AV_LAUNCH_CHECK();

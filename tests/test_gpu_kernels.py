@@ -65,9 +65,11 @@ def _check_history(loop, g, frame, L):
     ("tracker_sim720", {}, (60, 90, 150)),
     ("tracker_ties", dict(iou_threshold=0.5, max_age=2, min_hits=1, trajectory_length=5), (40, 120)),
 ])
-@pytest.mark.parametrize("tcap", [64, 128])
-def test_tracker_matches_reference_goldens(hot, golden, case, kw, windows, tcap):
+@pytest.mark.parametrize("tcap,rep", [(64, None), (64, "1"), (128, None)])
+def test_tracker_matches_reference_goldens(hot, golden, case, kw, windows, tcap, rep, monkeypatch):
     import torch
+    if rep is not None:                      # one wave per stream instead of the 8 replica waves
+        monkeypatch.setenv("AVHOT_TRACKER_REP", rep)
     g = golden(case)
     L = kw.get("trajectory_length", 50)
     f0 = 0
