@@ -31,6 +31,7 @@ __host__ __device__ inline size_t state_bytes(int tcap, int L) {
 
 struct Row {
     int id, x1, y1, x2, y2, cls, age, hits, misses, slot, hlen;
+    int hpos;          // hlen % trajectory_length, kept incrementally (no integer divide in the frame loop)
     double conf;
 };
 
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         const av_track_row g = rows[row];
         r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
         r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+        r.hpos = g.hist_len % L;
         r.conf = g.conf;
     }
     // Retire the table loads here.  Otherwise the compiler places their wait at the first use inside
@@ -152,9 +154,10 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
     if (row < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
     lds_sync<MULTIWAVE>();
 
+    int fl = -1;                               // frame within the staged chunk
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
-        const int fl = f % FC;
+        fl = (fl + 1 == FC) ? 0 : fl + 1;
         if (fl == 0) {
             // one cooperative load of the next FC frames' detections; the only global reads of the loop
             const int nfr = (n_frames - f) < FC ? (n_frames - f) : FC;
@@ -399,9 +402,10 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.x1 = nx1, r.y1 = ny1, r.x2 = nx2, r.y2 = ny2;
                 r.conf = dconf[matched_j];
                 r.age += 1, r.hits += 1, r.misses = 0;
-                double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + (r.hlen % L)) * 4);
+                double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
                 if (!REPL || wid == 0) *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
                 r.hlen += 1;
+                r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
                 sh.d2t[matched_j] = r.id;
             } else {
                 r.age += 1, r.misses += 1;
@@ -438,6 +442,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.age = 0, r.hits = 1, r.misses = 0;
                 r.slot = sh.birth_slot[b];
                 r.hlen = 1;
+                r.hpos = (L == 1) ? 0 : 1;
                 double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
                 if (!REPL || wid == 0) *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
                 atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 av_track_row g;
                 g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
                 g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
-                g.flags = 0, g.conf = r.conf, g.reserved = 0.0;
+                g.flags = r.hpos, g.conf = r.conf, g.reserved = 0.0;      // flags carries hpos through the staging only
                 stage[pos] = g;
             }
             lds_sync<MULTIWAVE>();
@@ -487,6 +492,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 const av_track_row g = stage[row];
                 r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
                 r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+                r.hpos = g.flags;
                 r.conf = g.conf;
             }
         }
