@@ -87,3 +87,27 @@ def test_device_frame_generator_matches_oracle(LaneDetector):
         got = out.cpu().numpy()
         for s in range(S):
             assert np.array_equal(got[s], synthetic_frame(h, w, s0 + s, fr)), (h, w, s)
+
+
+def test_synthetic_data_generator_class(LaneDetector):
+    """The reference generator's API surface, rendering on the device: frames == the shared integer formulas."""
+    import torch
+    from data.generators import SyntheticDataGenerator
+    from oracle.lane_ref import synthetic_frame
+    gen = SyntheticDataGenerator(width=640, height=480, fps=30, stream=3, n_streams=2)
+    f0, veh = gen.generate_frame_with_vehicles()
+    assert f0.dtype == np.uint8 and f0.shape == (480, 640, 3) and 3 <= len(veh) <= 6
+    assert np.array_equal(f0, synthetic_frame(480, 640, 3, 0))
+    x1, y1, x2, y2 = veh[-1]["bbox"]
+    assert tuple(f0[(y1 + y2) // 2, (x1 + x2) // 2]) == veh[-1]["color"]
+    frames = list(gen.generate_video_stream(2))
+    assert np.array_equal(frames[1], synthetic_frame(480, 640, 3, 2))
+    dev = gen.generate_device_frames()
+    torch.cuda.synchronize()
+    assert np.array_equal(dev[1].cpu().numpy(), synthetic_frame(480, 640, 4, 3))
+    ego = gen.generate_ego_motion(5)
+    assert len(ego) == 5 and len(ego[0]) == 4
+    tr = gen.generate_agent_trajectories(3, num_steps=10)
+    assert tr.shape == (3, 10, 2) and np.isfinite(tr).all()
+    gen.reset()
+    assert np.array_equal(gen.generate_frame_with_vehicles()[0], f0)
