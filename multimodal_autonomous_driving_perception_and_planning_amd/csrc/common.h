@@ -133,6 +133,8 @@ __device__ __forceinline__ unsigned long long wave_argmax_nonneg(double v, bool 
     const unsigned hi = valid ? (unsigned)__double2hiint(v) : 0u, lo = (unsigned)__double2loint(v);
     const unsigned mh = wave_max_u32(hi);
     const bool top = valid && hi == mh;
+    const unsigned long long bt = __ballot(top);
+    if (__popcll(bt) <= 1) return bt;              // the high words already single out the maximum
     const unsigned ml = wave_max_u32(top ? lo : 0u);
     return __ballot(top && lo == ml);
 }

@@ -18,7 +18,8 @@
 // hide, so REP waves each hold the same table (lane == row) and split the association by detection
 // column: wave w tests column w against every row and resolves that column's contest, the results
 // cross through LDS with one barrier per frame, and every wave then applies the identical update to its
-// own copy (private LDS scratch, no further communication).  Global writes are shared out by wave.
+// own copy (private LDS scratch, no further communication).  Global writes are shared out over the
+// waves that rarely own a column (5: det2trk, 6: histories, 7: snapshots; 0: persisted table).
 #include "common.h"
 
 namespace {
@@ -229,8 +230,18 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 if (pc == 1) {
                     winner = __ffsll((long long)m) - 1;
                 } else if (pc >= 2) {
-                    if (!have_v) v = c ? inter / uni : 0.0;                  // the reference's float64 divide (:105)
-                    winner = __ffsll((long long)wave_argmax_nonneg(v, c)) - 1;
+                    // Order the candidates by an f32 quotient first: |q/Q - 1| < 2^-21 (two conversions, v_rcp_f32
+                    // at 1 ulp, one multiply), so when every other candidate is more than 2^-19 below the largest
+                    // q the float64 quotients (:105) are ordered the same way, strictly -- no tie, no divide.
+                    const float q = c ? (float)inter * __builtin_amdgcn_rcpf((float)uni) : 0.0f;
+                    const unsigned qmax = wave_max_u32(__float_as_uint(q));          // q >= 0: bit patterns order like values
+                    const unsigned long long near = __ballot(c && q >= __uint_as_float(qmax) * (1.0f - 0x1p-19f));
+                    if (__popcll(near) == 1 && !have_v) {
+                        winner = __ffsll((long long)near) - 1;
+                    } else {
+                        if (!have_v) v = c ? inter / uni : 0.0;              // the reference's float64 divide (:105)
+                        winner = __ffsll((long long)wave_argmax_nonneg(v, c)) - 1;
+                    }
                 }
             }
             xb[lane * 8 + wid] = c ? (unsigned char)(1u << wid) : (unsigned char)0;
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.conf = dconf[matched_j];
                 r.age += 1, r.hits += 1, r.misses = 0;
                 double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
-                if (!REPL || wid == 0) *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                if (!REPL || wid == 6) *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
                 r.hlen += 1;
                 r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
                 sh.d2t[matched_j] = r.id;
@@ -444,7 +455,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.hlen = 1;
                 r.hpos = (L == 1) ? 0 : 1;
                 double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
-                if (!REPL || wid == 0) *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
+                if (!REPL || wid == 6) *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
                 atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
             }
             next_id += nb;
@@ -498,7 +509,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         }
 
         // ---- per-frame outputs --------------------------------------------------------------------
-        if (snap && (!REPL || wid == 1)) {
+        if (snap && (!REPL || wid == 7)) {
             if (row < T) {
                 av_track_row g;
                 g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
@@ -509,7 +520,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
             }
             if (row == 0) snap_n[sf] = T;
         }
-        if (det2trk && row < dcap && (!REPL || wid == 2)) det2trk[sf * dcap + row] = sh.d2t[row];
+        if (det2trk && row < dcap && (!REPL || wid == 5)) det2trk[sf * dcap + row] = sh.d2t[row];
         lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
     }
 
