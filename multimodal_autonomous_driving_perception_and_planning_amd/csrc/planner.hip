@@ -33,7 +33,43 @@ struct PlanParams {
     double dt, H;
     double w_lat, w_vel, w_acc, w_curv;
     const double *t, *alpha, *q, *dtd, *lat;
+    double atq[20];      // atan polynomial (kernel argument -> scalar registers, one per Horner step)
 };
+
+// atan(t) = t + t*z*Q(z), z = t*t, t in [0,1]: degree-19 Chebyshev interpolant of (atan(sqrt z)/sqrt z - 1)/z
+// derived in long double by tools/atan_poly.py; float64 Horner error <= 2.1 ulp over [0,1].
+static const double ATAN_Q[20] = {
+    -0x1.5555555555549p-2, 0x1.99999999979b9p-3,  -0x1.24924923e22b4p-3, 0x1.c71c718e5a102p-4,
+    -0x1.745d120df88fbp-4, 0x1.3b1362fc35ab5p-4,  -0x1.110deef367776p-4, 0x1.e1b3c8d50e91fp-5,
+    -0x1.ae2c7119eb922p-5, 0x1.81fdd2525246ap-5,  -0x1.56daf4786fd80p-5, 0x1.2575526b2309ap-5,
+    -0x1.d168e01adf666p-6, 0x1.462cc26bda000p-6,  -0x1.8055065b73333p-7, 0x1.693bd6b79999ap-8,
+    -0x1.fdf4e15cccccdp-10, 0x1.f224118000000p-12, -0x1.2568700000000p-14, 0x1.2ed799999999ap-18,
+};
+
+// atan2 for finite arguments of ordinary magnitude (waypoint deltas), |error| <= ~2 ulp like libm's.
+// NumPy's arctan2 is libm's, so this call is tolerance-matched either way; what this version avoids is
+// ocml's special-case handling and the ~40 moves that materialise its 64-bit constants per call.
+__device__ __forceinline__ double atan2_fast(double y, double x, const double (&Q)[20]) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const bool swap = ay > ax;
+    const double mx = swap ? ay : ax, mn = swap ? ax : ay;
+    // t = mn / mx: reciprocal refined twice (as the compiler's own f64 divide does), then one residual
+    // correction of the quotient -> correctly rounded but for astronomically rare operands
+    double r = __builtin_amdgcn_rcp(mx);
+    r = __builtin_fma(__builtin_fma(-mx, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-mx, r, 1.0), r, r);
+    double t = mn * r;
+    t = __builtin_fma(__builtin_fma(-t, mx, mn), r, t);
+    t = mx == 0.0 ? 0.0 : t;                                     // atan2(0, 0) = 0
+    const double z = t * t;
+    double pz = Q[19];
+#pragma unroll
+    for (int k = 18; k >= 0; --k) pz = __builtin_fma(pz, z, Q[k]);
+    double a = __builtin_fma(t * z, pz, t);
+    a = swap ? 1.5707963267948966 - a : a;
+    a = x < 0.0 ? 3.141592653589793 - a : a;
+    return __builtin_copysign(a, y);
+}
 
 __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
 
@@ -312,29 +348,46 @@ __global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_s
         const int f = f0 + g;
         const double* tg = trig + g * 8;
         const double x0 = tg[0], y0 = tg[1], cs = tg[2], sn = tg[3], c2 = tg[4], s2 = tg[5], h0 = tg[6];
+        // per speed k: everything the 7 lateral samples share, kept in registers so that the trajectories can
+        // be produced in memory order c = li*3 + k (a wave then writes its 51 KB sequentially; the speed-outer
+        // order hops 7344 B between tiles and costs a quarter of the write rate -- tools/wpattern.hip)
+        double kv[3], kbx[3], kby[3], kbx1[3], kby1[3], kden[3], krden[3], kb0[3], kb1[3], kb2[3];
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
             const double v = o[2 * li_c], s = o[2 * li_c + 1], s1 = o[2 * ln_c + 1];
-            const double bx = x0 + s * cs, by = y0 + s * sn;         // :175-176
-            const double bx1 = x0 + s1 * cs, by1 = y0 + s1 * sn;
-            const double den = v * p.dt + 1e-6;                      // :196 denominator
+            kv[k] = v;
+            kbx[k] = x0 + s * cs, kby[k] = y0 + s * sn;              // :175-176
+            kbx1[k] = x0 + s1 * cs, kby1[k] = y0 + s1 * sn;
+            kden[k] = v * p.dt + 1e-6;                               // :196 denominator
+            krden[k] = 1.0 / kden[k];                                // shared by the n_lat trajectories of this speed
             const double* b = base + (g * 3 + k) * 4;
-            const double b0 = b[0], b1 = b[1], b2 = b[2];
-            for (int li = 0; li < p.n_lat; ++li) {
+            kb0[k] = b[0], kb1[k] = b[1], kb2[k] = b[2];
+        }
+        for (int li = 0; li < p.n_lat; ++li) {
+            const double df = readlane_f64(lat_l, li);
+            const double d = df * q_i, d1 = df * q_n;
+            const double dxc = d * c2, dyc = d * s2, dxc1 = d1 * c2, dyc1 = d1 * s2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
                 const int c = li * 3 + k;
+                const double v = kv[k], bx = kbx[k], by = kby[k], bx1 = kbx1[k], by1 = kby1[k];
+                const double den = kden[k], rden = krden[k], b0 = kb0[k], b1 = kb1[k], b2 = kb2[k];
                 if (pending) {           // issue the LDS reads of the staged tile early; consumed after the math
                     wave_lds_fence();
                     const double2* src = reinterpret_cast<const double2*>(stage);
                     r0 = src[q0], r1 = src[q1], r2 = src[q2];
                     wave_lds_fence();
                 }
-                const double df = readlane_f64(lat_l, li);
-                const double d = df * q_i, d1 = df * q_n;
-                const double x = bx + d * c2, y = by + d * s2;       // :179-180
-                const double x1 = bx1 + d1 * c2, y1 = by1 + d1 * s2;
-                double hd = atan2(y1 - y, x1 - x);                   // :188
+                const double x = bx + dxc, y = by + dyc;             // :179-180
+                const double x1 = bx1 + dxc1, y1 = by1 + dyc1;
+                double hd = atan2_fast(y1 - y, x1 - x, p.atq);       // :188
                 const double hprev = dpp_mov_f64<0x138>(hd);         // lane i <- lane i-1
-                double curv = (hd - hprev) / den;
+                // (hd - hprev) / den, correctly rounded from the correctly rounded reciprocal (Markstein):
+                // q0 = a*r, q = q0 + (a - q0*den)*r
+                const double dh = hd - hprev;
+                const double cq = dh * rden;
+                double curv = __builtin_fma(__builtin_fma(-cq, den, dh), rden, cq);
                 curv = (lane > 0 && lane < n - 1) ? curv : 0.0;
                 if (lane == n - 1) hd = n > 1 ? hprev : h0;          // :190
                 double lat_sum = 0.0, obs_sum = 0.0;
@@ -510,6 +563,7 @@ static void fill_params(const av_ctx* ctx, PlanParams& p) {
     p.w_lat = ctx->pcfg.w_lateral, p.w_vel = ctx->pcfg.w_velocity, p.w_acc = ctx->pcfg.w_acceleration;
     p.w_curv = ctx->pcfg.w_curvature;
     p.t = ctx->d_ptab, p.alpha = p.t + n, p.q = p.alpha + n, p.dtd = p.q + n, p.lat = p.dtd + n;
+    for (int k = 0; k < 20; ++k) p.atq[k] = ATAN_Q[k];
 }
 
 extern "C" {
