@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"])
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default by workload)")
     ap.add_argument("--window", type=int, default=None, help="frames per stream per step")
@@ -144,7 +144,7 @@ def main():
     from oracle.harness_ref import ego_motion
 
     S = a.streams or (1 if a.workload == "config2" else 64)
-    W = a.window or (32768 if a.workload == "config2" else 256)
+    W = a.window or (131072 if a.workload == "config2" else 256)
     loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True)
     L = nat.lib()
     g0 = rank * S                                      # global stream ids of this rank
