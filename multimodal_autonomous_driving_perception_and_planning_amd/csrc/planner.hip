@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
     }
 }
 
+// Output ring of planner_wave_kernel: 256 units of 16 B.  It holds at most 63 carried units + one tile of
+// 3n <= 192 units; FPW*3*n <= 384 doubles of phase-1 scratch also fit.
+constexpr int RING_UNITS = 256, RING_DOUBLES = RING_UNITS * 2;
+
 // Throughput variant for large batches and n <= 64: every wave is autonomous (no workgroup barrier).
 // A wave owns FPW consecutive start states; lane = waypoint index, so the per-waypoint constants
 // (1-exp(-t_i), quintic blend, timestamp) sit in registers for the whole kernel.
@@ -251,10 +255,10 @@ __global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_s
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = p.n, C = p.C;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const size_t per_wave = (size_t)FPW * 3 * n * 2 + (size_t)n * 6 + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
+    const size_t per_wave = (size_t)FPW * 3 * n * 2 + RING_DOUBLES + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
     double* vs = sm + wid * per_wave;                  // [FPW*3][n][2]  (v, s)
-    double* stage = vs + (size_t)FPW * 3 * n * 2;      // [n][6] AoS tile; phase 1: acc terms [FPW*3][n]
-    double* costs = stage + (size_t)n * 6;             // [FPW][C]
+    double* stage = vs + (size_t)FPW * 3 * n * 2;      // output ring (256 x 16 B); phase 1: acc terms [FPW*3][n]
+    double* costs = stage + RING_DOUBLES;              // [FPW][C]
     double* base = costs + even_up(FPW * C);           // [FPW*3][4]  S_v, S_a, running
     double* trig = base + FPW * 3 * 4;                 // [FPW][8]
     const long long gw = (long long)blockIdx.x * 4 + wid;
@@ -336,13 +340,18 @@ __global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_s
     // ---- 2 -----------------------------------------------------------------------------------------
     // Lanes >= n run the same arithmetic on a clamped index (no predication inside the loop); their
     // results are dropped at the sum and at the store.
-    // software pipeline over trajectories: tile(c) is staged in LDS at the end of iteration c and
-    // written to HBM during iteration c+1 (n*3 16-byte chunks: lanes, lanes+64, and a tail of `tail`).
-    const int n3 = n * 3;                                   // 16-byte chunks per trajectory (153 for n = 51)
-    const bool c0 = lane < n3, c1 = lane + 64 < n3, c2 = lane + 128 < n3;
-    const int q0 = c0 ? lane : 0, q1 = c1 ? lane + 64 : 0, q2 = c2 ? lane + 128 : 0;
-    bool pending = false;
-    double2* pdst = nullptr;
+    // Output stream.  The wave's trajectories are contiguous in HBM (memory order), 3n 16-byte units each.
+    // Tiles are appended to an LDS ring in stream order and leave as FULL 1-KB wave stores aligned in
+    // absolute address (only the very first and last store of the wave are partial): a 2448-B tile written
+    // as 64+64+25 lanes straddles cache lines at both ends and reaches 5.3 TB/s store-only, aligned full
+    // stores 6.0 (tools/wpattern.hip, tools/wfill.hip).  Software pipeline: the chunks completed by tile
+    // c-1 are read from the ring at the top of iteration c and stored after its arithmetic.
+    const int n3 = n * 3;                                   // units per trajectory (153 for n = 51)
+    const size_t G0 = (size_t)(reinterpret_cast<uintptr_t>(wp) >> 4) + (size_t)f0 * C * n3;   // unit address of the stream
+    const int A = (int)(G0 & 63);                           // stream unit u sits at virtual unit v = u + A
+    double2* const gch = reinterpret_cast<double2*>((G0 - (size_t)A) << 4);                   // virtual unit 0
+    double2* const ring = reinterpret_cast<double2*>(stage);
+    int ti = 0, jdone = 0;                                  // tiles staged, chunks stored
     double2 r0 = make_double2(0.0, 0.0), r1 = r0, r2 = r0;
     for (int g = 0; g < nf; ++g) {
         const int f = f0 + g;
@@ -373,10 +382,14 @@ __global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_s
                 const int c = li * 3 + k;
                 const double v = kv[k], bx = kbx[k], by = kby[k], bx1 = kbx1[k], by1 = kby1[k];
                 const double den = kden[k], rden = krden[k], b0 = kb0[k], b1 = kb1[k], b2 = kb2[k];
-                if (pending) {           // issue the LDS reads of the staged tile early; consumed after the math
+                const int jend = (A + ti * n3) >> 6;       // chunks complete once tiles < ti are staged
+                const int np = wp ? jend - jdone : 0;        // 0 (first tile) .. 3
+                if (np > 0) {            // issue the LDS reads early; consumed after the math
                     wave_lds_fence();
-                    const double2* src = reinterpret_cast<const double2*>(stage);
-                    r0 = src[q0], r1 = src[q1], r2 = src[q2];
+                    const int u0 = jdone * 64 + lane;
+                    r0 = ring[u0 & (RING_UNITS - 1)];
+                    if (np > 1) r1 = ring[(u0 + 64) & (RING_UNITS - 1)];
+                    if (np > 2) r2 = ring[(u0 + 128) & (RING_UNITS - 1)];
                     wave_lds_fence();
                 }
                 const double x = bx + dxc, y = by + dyc;             // :179-180
@@ -416,29 +429,32 @@ __global__ void __launch_bounds__(256) planner_wave_kernel(PlanParams p, int n_s
                     costs[g * C + c] = EXTRA ? (va + curv_sum) + obs_sum : va + curv_sum;
                 }
                 if (wp) {
-                    // The tile of the previous trajectory was read into r0..r2 at the top of this
-                    // iteration; stream it out now (contiguous 16 B per lane), then stage this one.
-                    if (pending) {
-                        if (c0) pdst[q0] = r0;
-                        if (c1) pdst[q1] = r1;
-                        if (c2) pdst[q2] = r2;
+                    // stream out the chunks read at the top of this iteration, then append this tile
+                    if (np > 0) {
+                        const int v0 = jdone * 64 + lane;
+                        if (v0 >= A) gch[v0] = r0;                       // only chunk 0 has units before the stream
+                        if (np > 1) gch[v0 + 64] = r1;
+                        if (np > 2) gch[v0 + 128] = r2;
+                        jdone = jend;
                     }
                     if (in) {
-                        double2* w = reinterpret_cast<double2*>(stage + (size_t)lane * 6);
-                        w[0] = make_double2(x, y), w[1] = make_double2(hd, v), w[2] = make_double2(t_i, curv);
+                        const int u = A + ti * n3 + lane * 3;
+                        ring[u & (RING_UNITS - 1)] = make_double2(x, y);
+                        ring[(u + 1) & (RING_UNITS - 1)] = make_double2(hd, v);
+                        ring[(u + 2) & (RING_UNITS - 1)] = make_double2(t_i, curv);
                     }
-                    pdst = reinterpret_cast<double2*>(wp + ((size_t)f * C + c) * n * 6);
-                    pending = true;
+                    ++ti;
                 }
             }
         }
     }
-    if (pending) {
+    if (wp) {                 // drain: remaining full chunks and the partial tail
         wave_lds_fence();
-        const double2* src = reinterpret_cast<const double2*>(stage);
-        if (c0) pdst[q0] = src[q0];
-        if (c1) pdst[q1] = src[q1];
-        if (c2) pdst[q2] = src[q2];
+        const int vend = A + ti * n3;
+        for (int j = jdone; j * 64 < vend; ++j) {
+            const int v = j * 64 + lane;
+            if (v >= A && v < vend) gch[v] = ring[v & (RING_UNITS - 1)];
+        }
     }
     wave_lds_fence();
     // ---- 3 -----------------------------------------------------------------------------------------
@@ -664,7 +680,7 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
     hipStream_t st = as_stream(stream);
     if (n <= 64 && n_states >= 1024) {
         constexpr int FPW = 2;
-        const size_t per_wave = (size_t)FPW * 3 * n * 2 + (size_t)n * 6 + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
+        const size_t per_wave = (size_t)FPW * 3 * n * 2 + RING_DOUBLES + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
         const size_t lds_w = per_wave * 4 * sizeof(double);
         if (lds_w <= 64 * 1024) {
             const int grid_w = (n_states + 4 * FPW - 1) / (4 * FPW);
