@@ -250,6 +250,56 @@ __global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t
     out[(size_t)p * cs_out + coff_out + c] = f2bf(m);
 }
 
+// SPPF's three chained 5x5/stride-1 max-pools (padding -inf) in one pass: pool(pool(x)) is the 9x9 window of x
+// and the third the 13x13 one, so all three come from one LDS copy of the map, separably (row maxima of
+// radius 2/4/6, then column maxima).  Workgroup = (image, 8-channel slab), thread = pixel, 16-byte accesses.
+__device__ __forceinline__ uint4 bf16x8_max(uint4 a, uint4 b) {
+    auto mx = [](unsigned u, unsigned v) {
+        const float lo = fmaxf(__uint_as_float(u << 16), __uint_as_float(v << 16));
+        const float hi = fmaxf(__uint_as_float(u & 0xFFFF0000u), __uint_as_float(v & 0xFFFF0000u));
+        return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+    };
+    return make_uint4(mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z), mx(a.w, b.w));
+}
+__global__ void __launch_bounds__(1024) sppf_pools_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out,
+                                                          int coff_out, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+    uint4* s0 = reinterpret_cast<uint4*>(pool_smem);          // [HW] input
+    uint4* s1 = s0 + H * W;                                   // [3][HW] row maxima of radius 2, 4, 6
+    const int n = blockIdx.x, c8 = blockIdx.y, t = threadIdx.x, HW = H * W;
+    const uint4 NEG = make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);     // bf16 -inf x8
+    const int y = t / W, x = t - y * W;
+    if (t < HW) s0[t] = *reinterpret_cast<const uint4*>(in + ((size_t)n * HW + t) * cs_in + coff_in + c8 * 8);
+    __syncthreads();
+    if (t < HW) {
+        uint4 m2 = NEG, m4 = NEG, m6 = NEG;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const uint4 v = s0[y * W + xx];
+            const int ad = dx < 0 ? -dx : dx;
+            m6 = bf16x8_max(m6, v);
+            if (ad <= 4) m4 = bf16x8_max(m4, v);
+            if (ad <= 2) m2 = bf16x8_max(m2, v);
+        }
+        s1[t] = m2, s1[HW + t] = m4, s1[2 * HW + t] = m6;
+    }
+    __syncthreads();
+    if (t < HW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = 2 + 2 * k;
+            uint4 m = NEG;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                m = bf16x8_max(m, s1[k * HW + yy * W + x]);
+            }
+            *reinterpret_cast<uint4*>(out + ((size_t)n * HW + t) * cs_out + coff_out + k * C + c8 * 8) = m;
+        }
+    }
+}
+
 __global__ void upsample2_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
                                  int H, int W, int C) {   // H, W: input size; output 2H x 2W, nearest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,60 +390,87 @@ __global__ void __launch_bounds__(1024) nms_sort_kernel(int A, float conf_thres,
 // (<= max_det rows of the suppression relation instead of all of it), and the next survivor is found by
 // scanning the removed bitmap.  Also maps the kept boxes back to the frame (scale_boxes) and truncation
 // is left to the caller (detector.py:111).
-__global__ void __launch_bounds__(1024) nms_greedy_kernel(int A, int max_det, float iou_thres, const float* __restrict__ sbox,
-                                                          const int* __restrict__ scount, const int* __restrict__ sidx,
-                                                          const float* __restrict__ cbox, const float* __restrict__ cconf,
-                                                          const int* __restrict__ ccls, float gain, float padx, float pady,
-                                                          float fw, float fh, int* __restrict__ det_n,
-                                                          float* __restrict__ det_box, float* __restrict__ det_conf,
-                                                          int* __restrict__ det_cls) {
+__device__ __forceinline__ bool nms_over(const float4 a, float aa, const float4 b, float bb, float thr) {
+    // a = the earlier (higher-score) box; same float32 expression and operand order as the oracle
+    const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+    const float inter = fmaxf(xx2 - xx1, 0.f) * fmaxf(yy2 - yy1, 0.f);
+    return inter / (aa + bb - inter) > thr;
+}
+
+// Greedy NMS over the sorted candidates, one workgroup of NMS_WAVES waves per image.  Candidates are taken 64
+// at a time (lane = candidate).  Every wave tests the chunk against its share of the boxes kept so far
+// (kept box k belongs to wave k % NMS_WAVES; boxes broadcast from LDS) and the per-wave survivor masks are
+// AND-ed; wave 0 then lets the chunk resolve itself in order with a ballot loop over its still-alive
+// members and appends the survivors.  Identical decisions to box-at-a-time greedy suppression (a box is
+// dropped iff an earlier KEPT box overlaps it), with two barriers per 64 candidates instead of per kept box.
+constexpr int NMS_WAVES = 16;
+__global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
+    int A, int max_det, float iou_thres, const float* __restrict__ sbox, const int* __restrict__ scount,
+    const int* __restrict__ sidx, const float* __restrict__ cbox, const float* __restrict__ cconf,
+    const int* __restrict__ ccls, float gain, float padx, float pady, float fw, float fh, int* __restrict__ det_n,
+    float* __restrict__ det_box, float* __restrict__ det_conf, int* __restrict__ det_cls) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
-    float4* bx = reinterpret_cast<float4*>(nms_smem);                       // [cnt]
-    unsigned* removed = reinterpret_cast<unsigned*>(bx + A);                 // [(A+31)/32]
-    __shared__ int cur;
-    const int n = blockIdx.x, t = threadIdx.x, cnt = scount[n];
-    const int words = (cnt + 31) >> 5;
-    for (int i = t; i < cnt; i += 1024) bx[i] = reinterpret_cast<const float4*>(sbox)[(size_t)n * A + i];
-    for (int i = t; i < words; i += 1024) removed[i] = 0;
-    if (t == 0) cur = 0;
-    __syncthreads();
+    float4* kbx = reinterpret_cast<float4*>(nms_smem);                      // kept boxes [max_det]
+    float* kar = reinterpret_cast<float*>(kbx + max_det);                   // their areas
+    int* kix = reinterpret_cast<int*>(kar + max_det);                       // their position in the sorted list
+    __shared__ unsigned long long amask[NMS_WAVES];
+    __shared__ int s_kept;
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, cnt = scount[n];
+    const float4* sb = reinterpret_cast<const float4*>(sbox) + (size_t)n * A;
     int kept = 0;
-    while (kept < max_det) {
-        // next candidate that is still alive (thread 0 scans the bitmap from `cur`)
-        if (t == 0) {
-            int i = cur;
-            while (i < cnt) {
-                const unsigned wv = ~removed[i >> 5] & (~0u << (i & 31));
-                if (wv) { i = (i & ~31) + __ffs((int)wv) - 1; break; }
-                i = (i & ~31) + 32;
+    float4 b = lane < cnt ? sb[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < cnt && kept < max_det; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < cnt;
+        const float bb = (b.z - b.x) * (b.w - b.y);
+        const int inext = i + 64;                      // next chunk's boxes are in flight during this one
+        const float4 bnext = inext < cnt ? sb[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool alive = valid;
+        for (int k = wid; k < kept; k += NMS_WAVES)
+            if (nms_over(kbx[k], kar[k], b, bb, iou_thres)) alive = false;
+        const unsigned long long mine = __ballot(alive);
+        if (lane == 0) amask[wid] = mine;
+        __syncthreads();
+        if (wid == 0) {
+            unsigned long long m = ~0ull;
+#pragma unroll
+            for (int w = 0; w < NMS_WAVES; ++w) m &= amask[w];
+            alive = (m >> lane) & 1ull;
+            unsigned long long todo = m;
+            while (todo) {
+                const int li = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                float4 a;
+                a.x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.x), li));
+                a.y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.y), li));
+                a.z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.z), li));
+                a.w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.w), li));
+                const float aa = (a.z - a.x) * (a.w - a.y);
+                if (lane > li && alive && nms_over(a, aa, b, bb, iou_thres)) alive = false;
+                m = __ballot(alive);
+                todo &= m;                       // a member suppressed just now no longer suppresses anyone
             }
-            cur = i < cnt ? i : cnt;
+            const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+            if (alive && pos < max_det) kbx[pos] = b, kar[pos] = bb, kix[pos] = i;
+            int nk = kept + __popcll(m);
+            nk = nk > max_det ? max_det : nk;
+            if (lane == 0) s_kept = nk;
         }
         __syncthreads();
-        const int i = cur;
-        if (i >= cnt) break;
-        const float4 a = bx[i];
-        const float aa = (a.z - a.x) * (a.w - a.y);
-        for (int j = i + 1 + t; j < cnt; j += 1024) {
-            const float4 b = bx[j];
-            const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
-            const float inter = fmaxf(xx2 - xx1, 0.f) * fmaxf(yy2 - yy1, 0.f);
-            if (inter / (aa + (b.z - b.x) * (b.w - b.y) - inter) > iou_thres) atomicOr(&removed[j >> 5], 1u << (j & 31));
-        }
-        if (t == 0) {
-            const int an = sidx[(size_t)n * A + i];
-            const float* b = cbox + ((size_t)n * A + an) * 4;
-            float* o = det_box + ((size_t)n * max_det + kept) * 4;
-            o[0] = fminf(fmaxf((b[0] - padx) / gain, 0.f), fw), o[1] = fminf(fmaxf((b[1] - pady) / gain, 0.f), fh);
-            o[2] = fminf(fmaxf((b[2] - padx) / gain, 0.f), fw), o[3] = fminf(fmaxf((b[3] - pady) / gain, 0.f), fh);
-            det_conf[(size_t)n * max_det + kept] = cconf[(size_t)n * A + an];
-            det_cls[(size_t)n * max_det + kept] = ccls[(size_t)n * A + an];
-            cur = i + 1;
-        }
-        ++kept;
-        __syncthreads();
+        kept = s_kept;
+        b = bnext;
     }
-    if (t == 0) det_n[n] = kept;
+    // the detections, all at once (the gathers through sidx would otherwise sit in the chunk loop's critical path)
+    for (int pos = threadIdx.x; pos < kept; pos += 64 * NMS_WAVES) {
+        const int an = sidx[(size_t)n * A + kix[pos]];
+        const float* c = cbox + ((size_t)n * A + an) * 4;
+        float* o = det_box + ((size_t)n * max_det + pos) * 4;
+        o[0] = fminf(fmaxf((c[0] - padx) / gain, 0.f), fw), o[1] = fminf(fmaxf((c[1] - pady) / gain, 0.f), fh);
+        o[2] = fminf(fmaxf((c[2] - padx) / gain, 0.f), fw), o[3] = fminf(fmaxf((c[3] - pady) / gain, 0.f), fh);
+        det_conf[(size_t)n * max_det + pos] = cconf[(size_t)n * A + an];
+        det_cls[(size_t)n * max_det + pos] = ccls[(size_t)n * A + an];
+    }
+    if (threadIdx.x == 0) det_n[n] = kept;
 }
 
 // ---- host side: graph of layers --------------------------------------------------------------------------------
@@ -565,7 +642,11 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     CV(Slice{cat11, 256, 128}, Slice{b7, 0, 256}, 3, 2, true, nullptr, 0, nullptr);               // 7
     ok = ok && add_c2f(y, Slice{b7, 0, 256}, Slice{b8, 0, 256}, 1, true);                          // 8
     CV(Slice{b8, 0, 256}, Slice{spp, 0, 128}, 1, 1, true, nullptr, 0, nullptr);                   // 9 SPPF cv1
-    for (int i = 0; i < 3; ++i) add_simple(y, 1, Slice{spp, 128 * i, 128}, Slice{spp, 128 * (i + 1), 128}, H / 32, W / 32, 128);
+    if ((H / 32) * (W / 32) <= 1024) {       // all three pools from one LDS copy of the map
+        add_simple(y, 3, Slice{spp, 0, 128}, Slice{spp, 128, 384}, H / 32, W / 32, 128);
+    } else {
+        for (int i = 0; i < 3; ++i) add_simple(y, 1, Slice{spp, 128 * i, 128}, Slice{spp, 128 * (i + 1), 128}, H / 32, W / 32, 128);
+    }
     CV(Slice{spp, 0, 512}, Slice{cat20, 128, 256}, 1, 1, true, nullptr, 0, nullptr);              // 9 SPPF cv2 -> cat20[128:384]
     add_simple(y, 2, Slice{cat20, 128, 256}, Slice{cat11, 0, 256}, H / 32, W / 32, 256);           // 10 upsample -> cat11[0:256]
     ok = ok && add_c2f(y, Slice{cat11, 0, 384}, Slice{cat17, 64, 128}, 1, false);                  // 12 -> cat17[64:192]
@@ -612,9 +693,6 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    // the NMS kernel keeps all sorted boxes in LDS (16 B each): above the default 64 KB dynamic limit
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_greedy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((size_t)y.A * 16 + (size_t)((y.A + 31) / 32) * 4 + 16)));
     (void)hipDeviceSynchronize();
     *out = h;
     return AV_OK;
@@ -648,7 +726,8 @@ int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C,
 int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float conf_thres, float iou_thres, int max_det,
                     int32_t* det_n, float* det_box, float* det_conf, int32_t* det_cls) {
     AV_REQUIRE(h && bgr && det_n && det_box && det_conf && det_cls, AV_EINVAL, "av_yolo_forward: null argument");
-    AV_REQUIRE(max_det > 0 && conf_thres > 0.f, AV_EINVAL, "av_yolo_forward: max_det and conf_thres must be > 0");
+    AV_REQUIRE(max_det > 0 && max_det <= 2500 && conf_thres > 0.f, AV_EINVAL,
+               "av_yolo_forward: max_det must be in [1,2500] (kept boxes live in LDS) and conf_thres > 0");
     Yolo& y = h->y;
     hipStream_t st = as_stream(stream);
     const int B = y.B;
@@ -686,6 +765,10 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                 const int n = B * op.H * op.W * op.C;
                 hipLaunchKernelGGL(maxpool5_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bi.p, bi.C, op.in.coff, bo.p, bo.C,
                                    op.out.coff, B, op.H, op.W, op.C);
+            } else if (op.kind == 3) {
+                const int hw = op.H * op.W;
+                hipLaunchKernelGGL(sppf_pools_kernel, dim3(B, op.C / 8), dim3((hw + 63) / 64 * 64), (size_t)hw * 64, st, bi.p, bi.C,
+                                   op.in.coff, bo.p, bo.C, op.out.coff, op.H, op.W, op.C);
             } else {
                 const int n = B * 4 * op.H * op.W * (op.C / 8);
                 hipLaunchKernelGGL(upsample2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bi.p, bi.C, op.in.coff, bo.p, bo.C,
@@ -709,8 +792,8 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     // gain/pad of ultralytics scale_boxes
     const float gain = std::fmin((float)y.H / y.inH, (float)y.W / y.inW);
     const float padx = (float)std::lround((y.W - y.inW * gain) / 2 - 0.1), pady = (float)std::lround((y.H - y.inH * gain) / 2 - 0.1);
-    const size_t nms_lds = (size_t)y.A * 16 + (size_t)((y.A + 31) / 32) * 4 + 16;
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(1024), nms_lds, st, y.A, max_det, iou_thres, y.sbox, y.scount, y.sidx,
+    const size_t nms_lds = (size_t)max_det * 24;
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(64 * NMS_WAVES), nms_lds, st, y.A, max_det, iou_thres, y.sbox, y.scount, y.sidx,
                        y.cbox, y.cconf, y.ccls, gain, padx, pady, (float)y.inW, (float)y.inH, det_n, det_box, det_conf, det_cls);
     AV_LAUNCH_CHECK();
     return AV_OK;
