@@ -165,9 +165,10 @@ def main():
         if a.graph:
             loop.step(graph=True)
         else:
+            # side stream: detect -> track (stream order alone keeps steps apart there); main: kf -> plan; join.
+            # No fork is needed outside graph capture: nothing on the side stream depends on the main one.
             h, s = loop.ctx.handle, loop._s
-            loop.enqueue_detect()
-            nat.check(L.av_fork(h, s))
+            loop.enqueue_detect(loop.ctx.side_stream)
             loop.enqueue_track(loop.ctx.side_stream)
             loop.enqueue_kf()
             if timed:

@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames
     __shared__ __attribute__((aligned(16))) double zl[KF_BATCH][4];
     __shared__ __attribute__((aligned(16))) double raw[KF_BATCH][RAW];
     __shared__ int ml[KF_BATCH];
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of throughput kernels on the same SIMD
     const int s = blockIdx.x, lane = threadIdx.x;
     double* st = kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
 

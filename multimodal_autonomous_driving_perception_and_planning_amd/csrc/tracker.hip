@@ -128,6 +128,8 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
     constexpr int XB = 576;
     unsigned char* xchg = reinterpret_cast<unsigned char*>(c_area + (size_t)FC * dcap);
 
+    // a dependent per-frame chain: let these few waves issue ahead of throughput kernels sharing the SIMD
+    __builtin_amdgcn_s_setprio(3);
     const int s = blockIdx.x;
     const int nwaves = (tcap + 63) >> 6;
     const int L = cfg.trajectory_length;

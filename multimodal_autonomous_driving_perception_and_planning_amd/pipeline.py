@@ -118,10 +118,11 @@ class HotLoop:
                                          nat.ptr(self.cost), nat.ptr(self.order)))
 
     def enqueue_step(self):
-        """One window of the whole loop: detect; fork{track} || {kf; plan}; join."""
+        """One window of the whole loop: fork{detect; track} || {kf; plan}; join.  Detections only feed the
+        tracker, so both sit on the side stream and the Kalman/planner chain starts at once."""
         h, L, s = self.ctx.handle, self.L, self._s
-        self.enqueue_detect()
         nat.check(L.av_fork(h, s))
+        self.enqueue_detect(self.ctx.side_stream)
         self.enqueue_track(self.ctx.side_stream)
         self.enqueue_kf()
         self.enqueue_plan()
