@@ -131,12 +131,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 // once per wave.  Wave w computes output rows 2w, 2w+1 of the tile (16 columns each).
 constexpr int LT_H = 8, LT_W = 16, LT_CK = 32, LT_PIXB = LT_CK * 2 + 16;
 
-template <int MT>
+template <int MT, int KS>     // KS: kernel size (1 or 3), stride 1
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    const int taps = a.ksz * a.ksz, pad = a.ksz >> 1, s = a.stride;
-    const int PH = (LT_H - 1) * s + a.ksz, PW = (LT_W - 1) * s + a.ksz;
-    const int wrowb = taps * LT_CK * 2 + 16;
+    constexpr int taps = KS * KS, pad = KS >> 1, s = 1;
+    constexpr int PH = LT_H - 1 + KS, PW = LT_W - 1 + KS;
+    constexpr int wrowb = taps * LT_CK * 2 + 16;
     unsigned char* patch = lsm;
     unsigned char* wts = lsm + (((size_t)PH * PW * LT_PIXB + 15) & ~size_t(15));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
@@ -150,25 +150,58 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     f32x4 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
-        __syncthreads();
-        for (int i = tid; i < PH * PW * 4; i += 256) {
+    // Staging plan of this thread, fixed for the whole K loop: which 16-byte pieces of the input patch and
+    // of the weight slab it moves, as global element offsets (chunk offset c0 added per trip) and LDS byte
+    // offsets.  The divisions live here, once; the K loop then only issues loads, and the NEXT chunk's
+    // loads are in flight (in registers) while the current chunk's MFMAs run.
+    constexpr int NP = (PH * PW * 4 + 255) / 256, NW = (16 * MT * taps * 4 + 255) / 256;
+    const int part8 = (tid & 3) * 8;           // every piece of this thread is the same 8-channel part of a chunk
+    int p_g[NP], p_l[NP], w_g[NW], w_l[NW];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i = tid + k * 256;
+        p_g[k] = -1, p_l[k] = -1;
+        if (i < PH * PW * 4) {
             const int pix = i >> 2, part = i & 3;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = iy_org + py, ix = ix_org + px;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + c0 + part * 8);
-            *reinterpret_cast<uint4*>(patch + (size_t)pix * LT_PIXB + part * 16) = v;
+            p_l[k] = pix * LT_PIXB + part * 16;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) p_g[k] = ((n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8;
         }
-        for (int i = tid; i < 16 * MT * taps * 4; i += 256) {
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int i = tid + k * 256;
+        w_g[k] = -1, w_l[k] = 0;
+        if (i < 16 * MT * taps * 4) {
             const int row = i / (taps * 4), rem = i - row * taps * 4, tap = rem >> 2, part = rem & 3;
-            *reinterpret_cast<uint4*>(wts + (size_t)row * wrowb + (tap * LT_CK + part * 8) * 2) =
-                *reinterpret_cast<const uint4*>(a.wgt + (size_t)(ch_base + row) * a.kpad + tap * a.cin + c0 + part * 8);
+            w_l[k] = row * wrowb + (tap * LT_CK + part * 8) * 2;
+            w_g[k] = (ch_base + row) * a.kpad + tap * a.cin + part * 8;
         }
+    }
+    uint4 pv[NP], wv[NW];
+    auto gload = [&](int c0) {
+        const bool inch = c0 + part8 < a.cin;  // cin need not be a multiple of the chunk: the tail is zero-filled
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            pv[k] = (p_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(a.in + (size_t)p_g[k] + c0) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            wv[k] = (w_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(a.wgt + (size_t)w_g[k] + c0) : make_uint4(0, 0, 0, 0);
+    };
+    gload(0);
+    for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
+        __syncthreads();                        // every wave is done reading the previous chunk
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (p_l[k] >= 0) *reinterpret_cast<uint4*>(patch + p_l[k]) = pv[k];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (w_g[k] >= 0) *reinterpret_cast<uint4*>(wts + w_l[k]) = wv[k];
         __syncthreads();
+        if (c0 + LT_CK < a.cin) gload(c0 + LT_CK);
         for (int tap = 0; tap < taps; ++tap) {
-            const int ky = a.ksz == 1 ? 0 : tap / 3, kx = a.ksz == 1 ? 0 : tap - ky * 3;
+            const int ky = KS == 1 ? 0 : tap / 3, kx = KS == 1 ? 0 : tap - ky * 3;
             bf16x8 A[MT], B[2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -689,10 +722,14 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         return AV_EINVAL;
     }
     // stride-2 3x3 tiles need 45 KB of patch + up to 47 KB of weights
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     (void)hipDeviceSynchronize();
     *out = h;
     return AV_OK;
@@ -740,16 +777,25 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     for (const Yolo::Op& op : y.ops) {
         if (op.kind == 0) {
             const ConvArgs& a = op.ca;
-            if (a.cin % LT_CK == 0 && a.stride == 1 && !getenv("AVHOT_CONV_DIRECT")) {
+            // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
+            // a partial 32-channel chunk is zero-filled) and for 1x1 with whole chunks; stride 2 and the rest stay direct
+            const bool lds_ok = a.stride == 1 && ((a.ksz == 3 && a.cin >= 16 && a.cin % 8 == 0) || (a.ksz == 1 && a.cin % LT_CK == 0));
+            if (lds_ok && !getenv("AVHOT_CONV_DIRECT")) {
                 const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
                 const int taps = a.ksz * a.ksz;
                 const int PH = (LT_H - 1) * a.stride + a.ksz, PW = (LT_W - 1) * a.stride + a.ksz;
                 const size_t lds = (((size_t)PH * PW * LT_PIXB + 15) & ~size_t(15)) + (size_t)16 * op.mt * (taps * LT_CK * 2 + 16);
                 const dim3 lgrid(tiles_x * tiles_y * B, a.cout / (16 * op.mt));
-                if (op.mt == 4) hipLaunchKernelGGL((conv_lds_kernel<4>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
-                else if (op.mt == 5) hipLaunchKernelGGL((conv_lds_kernel<5>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
-                else if (op.mt == 2) hipLaunchKernelGGL((conv_lds_kernel<2>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
-                else hipLaunchKernelGGL((conv_lds_kernel<1>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);
+#define AV_CONV_LDS(MTV)                                                                                         \
+    do {                                                                                                         \
+        if (a.ksz == 1) hipLaunchKernelGGL((conv_lds_kernel<MTV, 1>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y); \
+        else hipLaunchKernelGGL((conv_lds_kernel<MTV, 3>), lgrid, dim3(256), lds, st, a, tiles_x, tiles_y);          \
+    } while (0)
+                if (op.mt == 4) AV_CONV_LDS(4);
+                else if (op.mt == 5) AV_CONV_LDS(5);
+                else if (op.mt == 2) AV_CONV_LDS(2);
+                else AV_CONV_LDS(1);
+#undef AV_CONV_LDS
                 AV_LAUNCH_CHECK();
                 continue;
             }
