@@ -47,6 +47,9 @@ def synthetic_frame(h=720, w=1280, stream=0, frame=0):
         on = (~sky) & ((((y + 5 * frame) // 24) % 2) == 0) & (np.abs(x - xc) <= 1 + (6 * t) // den)
         for c in range(3):
             img[..., c] = np.where(on, 235, img[..., c])
+    from .generators import vehicle_boxes
+    for x1, y1, x2, y2, col in vehicle_boxes(h, w, stream, frame):
+        img[y1:y2, x1:x2] = col
     return img.astype(np.uint8)
 
 

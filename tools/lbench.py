@@ -4,7 +4,7 @@ import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
-from oracle.lane_ref import synthetic_frame
+from multimodal_autonomous_driving_perception_and_planning_amd.harness import synthetic_frame
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--streams", type=int, default=64)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
 from multimodal_autonomous_driving_perception_and_planning_amd.perception.yolo import YoloV8n
-from oracle.lane_ref import synthetic_frame
+from multimodal_autonomous_driving_perception_and_planning_amd.harness import synthetic_frame
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 B = a.batch
