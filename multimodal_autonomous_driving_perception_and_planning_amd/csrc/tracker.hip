@@ -18,8 +18,10 @@
 // hide, so REP waves each hold the same table (lane == row) and split the association by detection
 // column: wave w tests column w against every row and resolves that column's contest, the results
 // cross through LDS with one barrier per frame, and every wave then applies the identical update to its
-// own copy (private LDS scratch, no further communication).  Global writes are shared out over the
-// waves that rarely own a column (5: det2trk, 6: histories, 7: snapshots; 0: persisted table).
+// own copy (private LDS scratch, no further communication).  Only the LAST wave -- which owns a column
+// only when a frame has REP detections -- keeps complete rows (ids, ages, hits, confidences, history rings)
+// and does every global write; the others carry just what column ownership needs: boxes, miss counters
+// and the row count, kept in step by the same matches, births and order-preserving compactions.
 #include "common.h"
 
 namespace {
@@ -110,6 +112,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int row = REPL ? lane : tid;                 // table row this thread holds
+    const bool full = !REPL || wid == REP - 1;         // this wave keeps complete rows and writes the outputs
     // per replica: Shared | stage[tcap];  then the detection chunk;  then (REPL) the exchange buffers
     const size_t sh_bytes = (sizeof(Shared) + 63) & ~size_t(63);
     const size_t rep_bytes = sh_bytes + (size_t)tcap * sizeof(av_track_row);
@@ -157,6 +160,21 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
     if (row < T) atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
     lds_sync<MULTIWAVE>();
 
+    // snapshot rows, live count and detection->track ids of one frame, from the state as it stands
+    auto emit = [&](size_t sfo) {
+        if (snap) {
+            if (row < T) {
+                av_track_row g;
+                g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+                g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+                g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
+                g.conf = r.conf, g.reserved = 0.0;
+                snap[sfo * tcap + row] = g;
+            }
+            if (row == 0) snap_n[sfo] = T;
+        }
+        if (det2trk && row < dcap) det2trk[sfo * dcap + row] = sh.d2t[row];
+    };
     int fl = -1;                               // frame within the staged chunk
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
@@ -186,8 +204,10 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         const double* dconf = c_conf + (size_t)fl * dcap;
         const double* darea = c_area + (size_t)fl * dcap;
         frame_count += 1;
-        if (row < dcap) sh.d2t[row] = -1;
-        lds_sync<MULTIWAVE>();
+        if (full) {
+            if (row < dcap) sh.d2t[row] = -1;
+            lds_sync<MULTIWAVE>();
+        }
 
         // ---- association (multi_object_tracker.py:113-164) ------------------------------------
         unsigned long long used = 0;          // columns already taken; identical in every thread
@@ -408,18 +428,20 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         // ---- matched / missed (:182-211) ---------------------------------------------------------
         if (active) {
             if (matched_j >= 0) {
-                const int nx1 = dbox[matched_j * 4 + 0], ny1 = dbox[matched_j * 4 + 1];
-                const int nx2 = dbox[matched_j * 4 + 2], ny2 = dbox[matched_j * 4 + 3];
-                const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
-                const double ncx = (double)(nx1 + nx2) / 2.0, ncy = (double)(ny1 + ny2) / 2.0;
-                r.x1 = nx1, r.y1 = ny1, r.x2 = nx2, r.y2 = ny2;
-                r.conf = dconf[matched_j];
-                r.age += 1, r.hits += 1, r.misses = 0;
-                double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
-                if (!REPL || wid == 6) *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
-                r.hlen += 1;
-                r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
-                sh.d2t[matched_j] = r.id;
+                const int4 nb4 = *reinterpret_cast<const int4*>(dbox + matched_j * 4);
+                if (full) {
+                    const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
+                    const double ncx = (double)(nb4.x + nb4.z) / 2.0, ncy = (double)(nb4.y + nb4.w) / 2.0;
+                    r.conf = dconf[matched_j];
+                    r.age += 1, r.hits += 1;
+                    double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
+                    *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                    r.hlen += 1;
+                    r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
+                    sh.d2t[matched_j] = r.id;
+                }
+                r.x1 = nb4.x, r.y1 = nb4.y, r.x2 = nb4.z, r.y2 = nb4.w;
+                r.misses = 0;
             } else {
                 r.age += 1, r.misses += 1;
             }
@@ -431,7 +453,15 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         const int nb = __popcll(unm);
         int nb_fit = nb;
         if (T + nb > tcap) nb_fit = tcap - T, status |= 1;
-        if (nb > 0) {
+        if (nb > 0 && !full) {
+            // light copy: the new rows' boxes only
+            if (row >= T && row < T + nb_fit) {
+                const int4 b4 = *reinterpret_cast<const int4*>(dbox + nth_set_bit(unm, row - T) * 4);
+                r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
+                r.misses = 0;
+            }
+            T += nb_fit;
+        } else if (nb > 0) {
             // rank of each free history slot; the b-th birth takes the b-th free slot
             {
                 const unsigned word = sh.slot_bits[row >> 5];
@@ -457,7 +487,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.hlen = 1;
                 r.hpos = (L == 1) ? 0 : 1;
                 double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
-                if (!REPL || wid == 6) *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
+                *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
                 atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
             }
             next_id += nb;
@@ -491,43 +521,48 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                     total += sh.w_cnt[w];
                 }
             }
-            if (dead) atomicAnd(&sh.slot_bits[r.slot >> 5], ~(1u << (r.slot & 31)));
-            if (keep) {
-                av_track_row g;
-                g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
-                g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
-                g.flags = r.hpos, g.conf = r.conf, g.reserved = 0.0;      // flags carries hpos through the staging only
-                stage[pos] = g;
-            }
-            lds_sync<MULTIWAVE>();
-            T = total;
-            if (row < T) {
-                const av_track_row g = stage[row];
-                r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
-                r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
-                r.hpos = g.flags;
-                r.conf = g.conf;
+            if (!full) {
+                // light copy: boxes and miss counters move down the same way
+                int* ls = reinterpret_cast<int*>(stage);
+                if (keep) {
+                    *reinterpret_cast<int4*>(ls + pos * 8) = make_int4(r.x1, r.y1, r.x2, r.y2);
+                    ls[pos * 8 + 4] = r.misses;
+                }
+                lds_sync<MULTIWAVE>();
+                T = total;
+                if (row < T) {
+                    const int4 b4 = *reinterpret_cast<const int4*>(ls + row * 8);
+                    r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
+                    r.misses = ls[row * 8 + 4];
+                }
+            } else {
+                if (dead) atomicAnd(&sh.slot_bits[r.slot >> 5], ~(1u << (r.slot & 31)));
+                if (keep) {
+                    av_track_row g;
+                    g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+                    g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+                    g.flags = r.hpos, g.conf = r.conf, g.reserved = 0.0;      // flags carries hpos through the staging only
+                    stage[pos] = g;
+                }
+                lds_sync<MULTIWAVE>();
+                T = total;
+                if (row < T) {
+                    const av_track_row g = stage[row];
+                    r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
+                    r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+                    r.hpos = g.flags;
+                    r.conf = g.conf;
+                }
             }
         }
 
         // ---- per-frame outputs --------------------------------------------------------------------
-        if (snap && (!REPL || wid == 7)) {
-            if (row < T) {
-                av_track_row g;
-                g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
-                g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
-                g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
-                g.conf = r.conf, g.reserved = 0.0;
-                snap[sf * tcap + row] = g;
-            }
-            if (row == 0) snap_n[sf] = T;
-        }
-        if (det2trk && row < dcap && (!REPL || wid == 5)) det2trk[sf * dcap + row] = sh.d2t[row];
+        if (full) emit(sf);
         lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
     }
 
     // ---- persist ----------------------------------------------------------------------------------
-    if (REPL && wid != 0) return;
+    if (!full) return;
     if (row < T) {
         av_track_row g;
         g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
