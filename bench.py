@@ -78,10 +78,12 @@ def bench_config3(a, world, rank, local):
     t0 = time.perf_counter()
     for k in range(a.steps):
         loop.enqueue_generate(stream0=rank * S)
+        nat.check(L.av_fork(loop.ctx.handle, loop._s))           # lane chain beside the detector (both only read the frames)
+        loop.enqueue_lanes(loop.ctx.side_stream)
         nat.check(L.av_event_record(evs[k][0], loop._s))
         loop.enqueue_detect()
         nat.check(L.av_event_record(evs[k][1], loop._s))
-        loop.enqueue_lanes()
+        nat.check(L.av_join(loop.ctx.handle, loop._s))
     loop.synchronize()
     torch.cuda.synchronize()
     if world > 1:

@@ -243,15 +243,20 @@ class PerceptionLoop:
                                          nat.ptr(self.det_n), nat.ptr(self.det_box), nat.ptr(self.det_conf),
                                          nat.ptr(self.det_cls)))
 
-    def enqueue_lanes(self):
-        nat.check(self.L.av_lane_detect(self.ctx.handle, self._s, C.byref(self.lcfg), self.S, self.h, self.w,
+    def enqueue_lanes(self, stream=None):
+        nat.check(self.L.av_lane_detect(self.ctx.handle, stream or self._s, C.byref(self.lcfg), self.S, self.h, self.w,
                                         nat.ptr(self.frames), None, nat.ptr(self.ws), nat.ptr(self.lane_state),
                                         nat.ptr(self.poly), nat.ptr(self.pts), nat.ptr(self.info), nat.ptr(self.conf), 0))
 
     def step(self, sync=False):
+        """generate; fork{lanes} || {detect}; join.  The detector and the lane chain only share the frames: the
+        lane chain (mostly the sequential per-frame PPHT, one CU per frame) runs beside the convolutions."""
+        h = self.ctx.handle
         self.enqueue_generate()
+        nat.check(self.L.av_fork(h, self._s))
+        self.enqueue_lanes(self.ctx.side_stream)
         self.enqueue_detect()
-        self.enqueue_lanes()
+        nat.check(self.L.av_join(h, self._s))
         if sync:
             self.stream.synchronize()
 
