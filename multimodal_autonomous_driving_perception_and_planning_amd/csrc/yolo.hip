@@ -515,7 +515,10 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
-    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; };
+    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; };   // lane 1: internal side stream
+    hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int head_begin = -1;                 // first op of the head (everything before it is one dependency chain)
     std::vector<Op> ops;
     std::vector<void*> allocs;
     float* head_box[3] = {nullptr, nullptr, nullptr};
@@ -638,6 +641,9 @@ size_t av_yolo_param_count(void) {
 int av_yolo_destroy(av_yolo* h) {
     if (!h) return AV_OK;
     for (void* p : h->y.allocs) (void)hipFree(p);
+    if (h->y.side) (void)hipStreamDestroy(h->y.side);
+    if (h->y.ev_fork) (void)hipEventDestroy(h->y.ev_fork);
+    if (h->y.ev_join) (void)hipEventDestroy(h->y.ev_join);
     delete h;
     return AV_OK;
 }
@@ -698,12 +704,15 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         ok = ok && dev_alloc(y, (void**)&y.head_box[i], (size_t)batch * hh * ww * 64 * 4);
         ok = ok && dev_alloc(y, (void**)&y.head_cls[i], (size_t)batch * hh * ww * NC * 4);
         if (!ok) break;
+        if (i == 0) y.head_begin = (int)y.ops.size();
         CV(Slice{pl[i], 0, pc[i]}, Slice{ba, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{ba, 0, 64}, Slice{bb, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{bb, 0, 64}, Slice{-1, 0, 64}, 1, 1, false, y.head_box[i], 64, nullptr);
+        const size_t cls_first = y.ops.size();
         CV(Slice{pl[i], 0, pc[i]}, Slice{ca, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{ca, 0, NC}, Slice{cb, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{cb, 0, NC}, Slice{-1, 0, NC}, 1, 1, false, y.head_cls[i], NC, nullptr);
+        for (size_t q = cls_first; q < y.ops.size(); ++q) y.ops[q].lane = 1;       // own buffers, independent of the box branch
         y.A += hh * ww;
     }
 #undef CV
@@ -721,7 +730,11 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         av_set_error("av_yolo_create: graph construction failed (parameter blob / capacity mismatch)");
         return AV_EINVAL;
     }
-    // stride-2 3x3 tiles need 45 KB of patch + up to 47 KB of weights
+    if (!getenv("AVHOT_YOLO_SERIAL")) {
+        AV_HIP(hipStreamCreateWithFlags(&y.side, hipStreamNonBlocking));
+        AV_HIP(hipEventCreateWithFlags(&y.ev_fork, hipEventDisableTiming));
+        AV_HIP(hipEventCreateWithFlags(&y.ev_join, hipEventDisableTiming));
+    }
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -767,6 +780,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                "av_yolo_forward: max_det must be in [1,2500] (kept boxes live in LDS) and conf_thres > 0");
     Yolo& y = h->y;
     hipStream_t st = as_stream(stream);
+    const hipStream_t st_main = st;
     const int B = y.B;
     {
         const int n = B * y.H * y.W;
@@ -774,7 +788,13 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                            y.nw, y.top, y.left, y.bufs[0].p);
         AV_LAUNCH_CHECK();
     }
-    for (const Yolo::Op& op : y.ops) {
+    for (size_t oi = 0; oi < y.ops.size(); ++oi) {
+        const Yolo::Op& op = y.ops[oi];
+        if (y.side && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
+            AV_HIP(hipEventRecord(y.ev_fork, st_main));
+            AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
+        }
+        st = (y.side && op.lane) ? y.side : st_main;
         if (op.kind == 0) {
             const ConvArgs& a = op.ca;
             // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
@@ -822,6 +842,11 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             }
         }
         AV_LAUNCH_CHECK();
+    }
+    st = st_main;
+    if (y.side && y.head_begin >= 0) {                     // the decode reads both branches
+        AV_HIP(hipEventRecord(y.ev_join, y.side));
+        AV_HIP(hipStreamWaitEvent(st_main, y.ev_join, 0));
     }
     Level lv[3];
     int aoff = 0;
