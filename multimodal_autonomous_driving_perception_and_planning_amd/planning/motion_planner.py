@@ -25,16 +25,56 @@ class Waypoint:
     curvature: float = 0.0
 
 
-@dataclass
 class Trajectory:
-    """A planned trajectory (motion_planner.py:25-54).  Compared by value, like the reference's dataclass."""
-    waypoints: List[Waypoint]
-    cost: float = 0.0
-    is_feasible: bool = True
-    trajectory_type: str = "nominal"
+    """A planned trajectory (motion_planner.py:25-54): same constructor, fields, value equality and helpers as
+    the reference's dataclass.  Trajectories coming out of the planner carry their waypoints as one float64
+    [n, 6] array and build the `List[Waypoint]` on first access to `.waypoints` (21 x 51 Python objects per
+    plan() were most of its per-call cost); `get_positions`, `length`, `duration` read the array directly."""
+    __slots__ = ("_wps", "_arr", "cost", "is_feasible", "trajectory_type")
+
+    def __init__(self, waypoints: List[Waypoint], cost: float = 0.0, is_feasible: bool = True,
+                 trajectory_type: str = "nominal"):
+        self._wps, self._arr = waypoints, None
+        self.cost, self.is_feasible, self.trajectory_type = cost, is_feasible, trajectory_type
+
+    @classmethod
+    def _from_array(cls, arr, cost=0.0, trajectory_type="nominal"):
+        t = cls(None, cost=cost, trajectory_type=trajectory_type)
+        t._arr = arr
+        return t
+
+    @property
+    def waypoints(self) -> List[Waypoint]:
+        if self._wps is None:
+            self._wps = [Waypoint(*row) for row in self._arr.tolist()]
+        return self._wps
+
+    @waypoints.setter
+    def waypoints(self, value):
+        self._wps, self._arr = value, None
+
+    def __eq__(self, other):
+        if other.__class__ is not self.__class__:
+            return NotImplemented
+        return (self.waypoints, self.cost, self.is_feasible, self.trajectory_type) == \
+               (other.waypoints, other.cost, other.is_feasible, other.trajectory_type)
+
+    __hash__ = None          # like an eq dataclass
+
+    def __repr__(self):
+        return "Trajectory(waypoints=%r, cost=%r, is_feasible=%r, trajectory_type=%r)" % (
+            self.waypoints, self.cost, self.is_feasible, self.trajectory_type)
 
     @property
     def length(self) -> float:
+        if self._wps is None:
+            if len(self._arr) < 2:
+                return 0.0
+            d = np.diff(self._arr[:, :2], axis=0)
+            total = 0.0
+            for v in np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2):      # same left-to-right sum as the reference's loop
+                total += v
+            return total
         if len(self.waypoints) < 2:
             return 0.0
         total = 0.0
@@ -44,11 +84,15 @@ class Trajectory:
 
     @property
     def duration(self) -> float:
+        if self._wps is None:
+            return float(self._arr[-1, 4] - self._arr[0, 4]) if len(self._arr) else 0.0
         if not self.waypoints:
             return 0.0
         return self.waypoints[-1].timestamp - self.waypoints[0].timestamp
 
     def get_positions(self) -> np.ndarray:
+        if self._wps is None:
+            return np.array(self._arr[:, :2])
         return np.array([[wp.x, wp.y] for wp in self.waypoints])
 
 
@@ -125,16 +169,19 @@ class MotionPlanner:
         vt = d.upload([float(target_velocity)], np.float64)
         wp = d.empty((1, self._n, nat.WP_DOUBLES), torch.float64)
         nat.check(d.lib.av_planner_generate(d.ctx.handle, d.stream, 1, nat.ptr(st), nat.ptr(df), nat.ptr(vt), nat.ptr(wp)))
-        return Trajectory(waypoints=_to_waypoints(wp.cpu().numpy()[0]))
+        return Trajectory._from_array(wp.cpu().numpy()[0])
 
     def evaluate_trajectory_cost(self, trajectory: Trajectory,
                                  obstacles: Optional[List[Tuple[float, float, float]]] = None) -> float:
-        if not trajectory.waypoints:
+        if (trajectory._wps is None and len(trajectory._arr) == 0) or (trajectory._wps is not None and not trajectory._wps):
             return float("inf")
         self._configure()
         d = self._dev
-        arr = np.array([[w.x, w.y, w.heading, w.velocity, w.timestamp, w.curvature] for w in trajectory.waypoints],
-                       np.float64)
+        if trajectory._wps is None:
+            arr = np.ascontiguousarray(trajectory._arr, np.float64)
+        else:
+            arr = np.array([[w.x, w.y, w.heading, w.velocity, w.timestamp, w.curvature] for w in trajectory.waypoints],
+                           np.float64)
         wp = d.upload(arr.reshape(1, -1, 6), np.float64)
         ref, nr = self._ref_arrays()
         obs, no = self._obs_arrays(d, obstacles)
@@ -161,7 +208,7 @@ class MotionPlanner:
         for c in range(self._c):
             lat = self._lat[c // 3]
             kind = "lane_keep" if abs(lat) < 0.5 else ("lane_change_left" if lat < 0 else "lane_change_right")
-            gen.append(Trajectory(waypoints=_to_waypoints(wph[c]), cost=float(costh[c]), trajectory_type=kind))
+            gen.append(Trajectory._from_array(wph[c], cost=float(costh[c]), trajectory_type=kind))
         candidates = [gen[int(c)] for c in orderh]
         return (candidates[0] if candidates else None), candidates
 
