@@ -257,6 +257,24 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
  * numbers, 0 = network input; 100+2i / 101+2i = float32 box / class logits of level i). */
 int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff);
 
+/* ---- T1: maneuver tags ------------------------------------------------------
+ * Replaces ManeuverDetector.detect (src/tagging/maneuver_detector.py:105-262): lateral / longitudinal /
+ * turning maneuver of every frame from the current and the 14 previous vehicle states (the reference looks
+ * at the newest 10 yaw rates and 15 headings of its 30-deep deques).  Enum fields are indices into the
+ * reference's Enum definition order (:18-41).  `state` carries the 14 states before the window per stream. */
+#define AV_MANEUVER_STATE_DOUBLES 32   /* frames seen, 14 yaw rates, 14 headings (oldest first), 3 spare */
+typedef struct av_maneuver_row {
+    int32_t lateral, longitudinal, turning, reserved;
+    double lateral_confidence, longitudinal_confidence, turning_confidence;
+    double speed_kmh, acceleration, yaw_rate_deg, timestamp;
+} av_maneuver_row;                      /* 72 bytes */
+int av_maneuver_reset(av_ctx* ctx, av_stream_t stream, int n_streams, double* state);
+/*   vstate      f64 [n_streams][n_frames][AV_VSTATE_DOUBLES]  (the out_state of av_kf_step)
+ *   lane_offset f64 [n_streams][n_frames], NaN = none for that frame; may be NULL (:197-203)
+ *   out         av_maneuver_row [n_streams][n_frames] */
+int av_maneuver_detect(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, const double* vstate,
+                       const double* lane_offset, double* state, av_maneuver_row* out);
+
 /* ---- synthetic input ---------------------------------------------------
  * Deterministic 8-bit BGR road scenes generated on the device, standing in for the reference's lost
  * SyntheticDataGenerator (data/generators, source absent).  Frame (stream0+s, frame) is bit-identical to

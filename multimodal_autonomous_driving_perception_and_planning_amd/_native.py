@@ -41,6 +41,11 @@ TRACK_ROW_FIELDS = [("id", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), 
 TRACK_ROW_BYTES = 64
 TRACKER_HDR_BYTES = 64
 KF_STATE_DOUBLES = 48
+MANEUVER_STATE_DOUBLES = 32
+MANEUVER_ROW_FIELDS = [("lateral", "<i4"), ("longitudinal", "<i4"), ("turning", "<i4"), ("reserved", "<i4"),
+                       ("lateral_confidence", "<f8"), ("longitudinal_confidence", "<f8"), ("turning_confidence", "<f8"),
+                       ("speed_kmh", "<f8"), ("acceleration", "<f8"), ("yaw_rate_deg", "<f8"), ("timestamp", "<f8")]
+MANEUVER_ROW_BYTES = 72
 VSTATE_DOUBLES = 12
 WP_DOUBLES = 6
 
@@ -81,6 +86,8 @@ _SIGS = [
     ("av_lane_workspace_view", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_size_t)]),
     ("av_synth_frames", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    ("av_maneuver_reset", C.c_int, [vp, vp, C.c_int, vp]),
+    ("av_maneuver_detect", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     ("av_yolo_param_count", C.c_size_t, []),
     ("av_yolo_create", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),
     ("av_yolo_destroy", C.c_int, [vp]),

@@ -112,6 +112,16 @@ class HotLoop:
                                     nat.ptr(self.z), None, nat.ptr(self.kf_state), nat.ptr(self.vstate),
                                     nat.ptr(self.plan_state)))
 
+    def enqueue_maneuver(self, stream=None, lane_offset=None):
+        """Maneuver tags of every frame of the window from the Kalman output (ManeuverDetector.detect,
+        maneuver_detector.py:105-262); call after enqueue_kf on the same stream.  Results: self.maneuver
+        (uint8 view of av_maneuver_row [S][W])."""
+        if not hasattr(self, "mv_state"):
+            self.mv_state = torch.zeros(self.S, nat.MANEUVER_STATE_DOUBLES, dtype=torch.float64, device=self.dev)
+            self.maneuver = torch.zeros(self.S, self.W, nat.MANEUVER_ROW_BYTES, dtype=torch.uint8, device=self.dev)
+        nat.check(self.L.av_maneuver_detect(self.ctx.handle, stream or self._s, self.S, self.W, nat.ptr(self.vstate),
+                                            nat.ptr(lane_offset), nat.ptr(self.mv_state), nat.ptr(self.maneuver)))
+
     def enqueue_plan(self, stream=None):
         nat.check(self.L.av_planner_plan(self.ctx.handle, stream or self._s, self.S * self.W,
                                          nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),

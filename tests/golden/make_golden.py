@@ -8,6 +8,7 @@ here do).  Importable reference stages:
   * src.perception.detector.ObjectDetector._detect_simulated   (detector.py:125-169)
   * src.tracking.MultiObjectTracker                            (multi_object_tracker.py:50-319)
   * src.planning.MotionPlanner                                 (motion_planner.py:57-374)
+  * src/tagging/maneuver_detector.py ManeuverDetector          (loaded from its file; NumPy only)
 
 `cv2` is absent here; detector.py imports it at module level but the simulated
 path never touches it, so an empty module object is registered under that name
@@ -285,11 +286,87 @@ def golden_planner(pln_mod):
     np.savez_compressed(os.path.join(OUT, "planner.npz"), **out)
 
 
+def _import_tagger(name):
+    """The tagging package's __init__ pulls in transformers/VLM code; the two rule-based detectors are plain
+    NumPy modules, so they are loaded straight from their files."""
+    import importlib.util
+    path = os.path.join(REF, "src", "tagging", name + ".py")
+    spec = importlib.util.spec_from_file_location("ref_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def maneuver_inputs():
+    """A state sequence that visits every branch of ManeuverDetector (maneuver_detector.py:105-262):
+    noisy cruise, steady yaw (lane-change rule), hard/normal braking, stop, acceleration, 90-degree turns,
+    curves, a u-turn whose heading change needs the +-360 normalisation, and lane offsets incl. None."""
+    rs = np.random.RandomState(11)
+    seg = []
+
+    def add(n, speed, acc, yaw, dhead, off):
+        seg.append((n, speed, acc, yaw, dhead, off))
+
+    add(40, 10.0, 0.0, 0.0, 0.0, None)                 # cruise, no offset
+    add(30, 10.0, 0.2, 0.12, 0.004, 0.3)               # steady left yaw > 5 deg/s
+    add(30, 10.0, -0.2, -0.12, -0.004, -0.3)           # steady right yaw
+    add(25, 9.0, -1.5, 0.0, 0.0, 0.7)                  # braking, offset left
+    add(25, 6.0, -3.6, 0.0, 0.0, -0.7)                 # hard braking, offset right
+    add(20, 0.2, 0.0, 0.0, 0.0, None)                  # stopped
+    add(25, 4.0, 1.6, 0.0, 0.0, 0.1)                   # accelerating
+    add(40, 8.0, 0.0, 0.6, 0.045, None)                # left turn (heading ramps ~0.63 rad per 14 frames -> curving/turning)
+    add(40, 8.0, 0.0, -0.6, -0.09, None)               # right turn, faster
+    add(30, 5.0, 0.0, 1.2, 0.2, None)                  # u-turn rate (> 120 deg per 14 frames, wraps past 180)
+    add(30, 10.0, 0.0, 0.3, 0.0, None)                 # instantaneous yaw-rate fallback (> 15 deg/s), no heading change
+    add(40, 10.0, 0.0, 0.0, 0.0, 0.51)                 # offset just over the threshold
+    states, offs = [], []
+    x = y = head = 0.0
+    for n, speed, acc, yaw, dhead, off in seg:
+        for _ in range(n):
+            head += dhead
+            x += speed * np.cos(head) / 30.0
+            y += speed * np.sin(head) / 30.0
+            states.append((speed + rs.normal(0, 0.02), head, acc + rs.normal(0, 0.05), yaw + rs.normal(0, 0.01), x, y))
+            offs.append(np.nan if off is None else off)
+    # a noisy stretch: yaw-rate std > 0.1 -> swerving
+    for _ in range(40):
+        head += rs.normal(0, 0.01)
+        states.append((10.0, head, rs.normal(0, 0.3), rs.normal(0, 0.25), x, y))
+        offs.append(np.nan)
+    return np.array(states, np.float64), np.array(offs, np.float64)
+
+
+def golden_maneuver():
+    mod = _import_tagger("maneuver_detector")
+    states, offs = maneuver_inputs()
+    det = mod.ManeuverDetector()
+    lat = [m for m in mod.LateralManeuver]
+    lon = [m for m in mod.LongitudinalManeuver]
+    trn = [m for m in mod.TurningManeuver]
+    idx = np.zeros((len(states), 3), np.int32)
+    val = np.zeros((len(states), 7), np.float64)
+    for i, (s, o) in enumerate(zip(states, offs)):
+        vs = types.SimpleNamespace(speed=s[0], heading=s[1], acceleration=s[2], yaw_rate=s[3], x=s[4], y=s[5])
+        t = det.detect(vs, None if np.isnan(o) else float(o))
+        idx[i] = (lat.index(t.lateral), lon.index(t.longitudinal), trn.index(t.turning))
+        val[i] = (t.lateral_confidence, t.longitudinal_confidence, t.turning_confidence, t.speed_kmh, t.acceleration,
+                  t.yaw_rate_deg, t.timestamp)
+    summary = det.get_maneuver_summary()
+    np.savez_compressed(os.path.join(OUT, "maneuver.npz"), states=states, lane_offset=offs, idx=idx, val=val,
+                        lateral_names=np.array([m.value for m in lat]), longitudinal_names=np.array([m.value for m in lon]),
+                        turning_names=np.array([m.value for m in trn]),
+                        summary_keys=np.array(sorted(summary)), summary_vals=np.array([summary[k] for k in sorted(summary)]))
+    print("maneuver.npz: %d frames; lateral %s longitudinal %s turning %s" % (
+        len(states), np.bincount(idx[:, 0], minlength=4), np.bincount(idx[:, 1], minlength=5), np.bincount(idx[:, 2], minlength=6)))
+
+
 def main():
     det_mod, trk_mod, pln_mod = _import_reference()
     dets = golden_detections(det_mod)
     golden_tracker(det_mod, trk_mod, dets)
     golden_planner(pln_mod)
+    golden_maneuver()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print("%-24s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -115,3 +115,15 @@ def test_planner_non_default_construction(golden):
 def test_detection_centers():
     b = np.array([[0, 519, 104, 597]])
     assert centers(b).tolist() == [[52.0, 558.0]]
+
+
+def test_maneuver_oracle_matches_reference(golden):
+    """ManeuverDetector through the real reference module (415 frames, every enum value): bit-for-bit."""
+    from oracle import maneuver_ref as M
+    g = golden("maneuver")
+    idx, val = M.run(g["states"], g["lane_offset"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(val, g["val"])
+    assert list(g["lateral_names"]) == list(M.LATERAL) and list(g["longitudinal_names"]) == list(M.LONGITUDINAL)
+    assert list(g["turning_names"]) == list(M.TURNING)
+    assert set(np.unique(idx[:, 0])) == {0, 1, 2, 3} and set(np.unique(idx[:, 1])) == {0, 1, 2, 3, 4}
+    assert set(np.unique(idx[:, 2])) == {0, 1, 2, 3, 4, 5}
