@@ -111,7 +111,8 @@ typedef struct {
     int32_t hist_len;            /* centres appended so far (birth included); ring index = k % L */
     int32_t flags;               /* bit0: confirmed (hits >= min_hits) */
     double conf;
-    double reserved;
+    float vx, vy;            /* last centre velocity (the Track.velocity property), valid when hist_len >= 2;
+                                differences of half-integers, so exact in float32 */
 } av_track_row;
 
 /* Persistent per-stream tracker state (device).  Layout, for stream s with capacity tcap, L =
@@ -274,6 +275,41 @@ int av_maneuver_reset(av_ctx* ctx, av_stream_t stream, int n_streams, double* st
  *   out         av_maneuver_row [n_streams][n_frames] */
 int av_maneuver_detect(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, const double* vstate,
                        const double* lane_offset, double* state, av_maneuver_row* out);
+
+/* ---- T2: interaction tags ----------------------------------------------------
+ * Replaces InteractionDetector.detect (src/tagging/interaction_detector.py:132-222) and its helpers
+ * (_estimate_distance :224, _estimate_relative_speed :250, _calculate_ttc :262, _analyze_interaction :270,
+ * _calculate_overall_risk :374): the consumer of the per-frame track tables.  The reference is handed the
+ * tracker's returned (confirmed) tracks in order; here those are the snapshot rows with flags bit0 set.  A
+ * track's centre-x history (deque of 30, needed by the cut-in rule) lives in `state`, indexed by the row's
+ * history slot, which is stable for a track's lifetime.  Types / risks are indices into the reference's Enum
+ * definition order (:20-40); type -1 = no interaction for that row. */
+typedef struct {
+    int32_t frame_h, frame_w;        /* frame_shape (:135), e.g. 720, 1280 */
+    int32_t class_kind[16];          /* per class id: 0 other, 1 pedestrian, 2 cyclist/bicycle, 3 car/truck/bus,
+                                        4 motorcycle (counted as a vehicle, :160, but outside the vehicle rules) */
+} av_interaction_cfg;
+typedef struct av_interaction_row {
+    int32_t type, risk, agent_id, cls;
+    double confidence, distance, relative_speed, ttc;       /* ttc NaN = None */
+} av_interaction_row;                /* 48 bytes */
+typedef struct av_interaction_summary {
+    int32_t agent_count, pedestrian_count, cyclist_count, vehicle_count;
+    int32_t n_interactions, primary_type, overall_risk, primary_row;   /* primary_type -1 = None */
+    double closest_distance, min_ttc, timestamp;                        /* min_ttc NaN = None */
+} av_interaction_summary;            /* 56 bytes */
+size_t av_interaction_state_bytes(int tcap);
+int av_interaction_reset(av_ctx* ctx, av_stream_t stream, int n_streams, int tcap, void* state);
+/*   snap, snap_n   the tracker's per-frame tables (av_tracker_update), tcap == 64
+ *   vstate         f64 [S][W][AV_VSTATE_DOUBLES] (ego speed = element 5); NULL = 10.0 (:166)
+ *   has_state      u8 [S][W], 0 = vehicle_state was None for that frame; NULL = always given
+ *   vy             f64 [S][W][tcap] image-space y velocity per row instead of the row's float vy; may be NULL
+ *   rows           av_interaction_row [S][W][tcap], aligned with the snapshot rows
+ *   summary        av_interaction_summary [S][W] */
+int av_interaction_detect(av_ctx* ctx, av_stream_t stream, const av_interaction_cfg* cfg, int n_streams, int n_frames,
+                          int tcap, const av_track_row* snap, const int32_t* snap_n, const double* vstate,
+                          const uint8_t* has_state, const double* vy, void* state, av_interaction_row* rows,
+                          av_interaction_summary* summary);
 
 /* ---- synthetic input ---------------------------------------------------
  * Deterministic 8-bit BGR road scenes generated on the device, standing in for the reference's lost

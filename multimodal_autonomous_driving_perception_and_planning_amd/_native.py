@@ -37,7 +37,7 @@ class LaneCfg(C.Structure):
 # numpy structured dtype mirroring av_track_row (64 bytes)
 TRACK_ROW_FIELDS = [("id", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("cls", "<i4"),
                     ("age", "<i4"), ("hits", "<i4"), ("misses", "<i4"), ("slot", "<i4"), ("hist_len", "<i4"),
-                    ("flags", "<i4"), ("conf", "<f8"), ("reserved", "<f8")]
+                    ("flags", "<i4"), ("conf", "<f8"), ("vx", "<f4"), ("vy", "<f4")]
 TRACK_ROW_BYTES = 64
 TRACKER_HDR_BYTES = 64
 KF_STATE_DOUBLES = 48
@@ -46,6 +46,18 @@ MANEUVER_ROW_FIELDS = [("lateral", "<i4"), ("longitudinal", "<i4"), ("turning", 
                        ("lateral_confidence", "<f8"), ("longitudinal_confidence", "<f8"), ("turning_confidence", "<f8"),
                        ("speed_kmh", "<f8"), ("acceleration", "<f8"), ("yaw_rate_deg", "<f8"), ("timestamp", "<f8")]
 MANEUVER_ROW_BYTES = 72
+INTERACTION_ROW_FIELDS = [("type", "<i4"), ("risk", "<i4"), ("agent_id", "<i4"), ("cls", "<i4"), ("confidence", "<f8"),
+                          ("distance", "<f8"), ("relative_speed", "<f8"), ("ttc", "<f8")]
+INTERACTION_ROW_BYTES = 48
+INTERACTION_SUMMARY_FIELDS = [("agent_count", "<i4"), ("pedestrian_count", "<i4"), ("cyclist_count", "<i4"),
+                              ("vehicle_count", "<i4"), ("n_interactions", "<i4"), ("primary_type", "<i4"),
+                              ("overall_risk", "<i4"), ("primary_row", "<i4"), ("closest_distance", "<f8"),
+                              ("min_ttc", "<f8"), ("timestamp", "<f8")]
+INTERACTION_SUMMARY_BYTES = 56
+
+
+class InteractionCfg(C.Structure):
+    _fields_ = [("frame_h", C.c_int32), ("frame_w", C.c_int32), ("class_kind", C.c_int32 * 16)]
 VSTATE_DOUBLES = 12
 WP_DOUBLES = 6
 
@@ -87,6 +99,9 @@ _SIGS = [
                                          C.POINTER(C.c_size_t)]),
     ("av_synth_frames", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_maneuver_reset", C.c_int, [vp, vp, C.c_int, vp]),
+    ("av_interaction_state_bytes", C.c_size_t, [C.c_int]),
+    ("av_interaction_reset", C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    ("av_interaction_detect", C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     ("av_maneuver_detect", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     ("av_yolo_param_count", C.c_size_t, []),
     ("av_yolo_create", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),

@@ -35,6 +35,7 @@ __host__ __device__ inline size_t state_bytes(int tcap, int L) {
 struct Row {
     int id, x1, y1, x2, y2, cls, age, hits, misses, slot, hlen;
     int hpos;          // hlen % trajectory_length, kept incrementally (no integer divide in the frame loop)
+    float vx, vy;      // last velocity (valid when hlen >= 2)
     double conf;
 };
 
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
         r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
         r.hpos = g.hist_len % L;
-        r.conf = g.conf;
+        r.conf = g.conf, r.vx = g.vx, r.vy = g.vy;
     }
     // Retire the table loads here.  Otherwise the compiler places their wait at the first use inside
     // the frame loop, where (vmcnt counts loads and stores in order) it would also drain the previous
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
                 g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
                 g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
-                g.conf = r.conf, g.reserved = 0.0;
+                g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;
                 snap[sfo * tcap + row] = g;
             }
             if (row == 0) snap_n[sfo] = T;
@@ -436,6 +437,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                     r.age += 1, r.hits += 1;
                     double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
                     *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                    r.vx = (float)(ncx - ocx), r.vy = (float)(ncy - ocy);
                     r.hlen += 1;
                     r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
                     sh.d2t[matched_j] = r.id;
@@ -486,6 +488,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                 r.slot = sh.birth_slot[b];
                 r.hlen = 1;
                 r.hpos = (L == 1) ? 0 : 1;
+                r.vx = 0.f, r.vy = 0.f;
                 double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
                 *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
                 atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                     av_track_row g;
                     g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
                     g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
-                    g.flags = r.hpos, g.conf = r.conf, g.reserved = 0.0;      // flags carries hpos through the staging only
+                    g.flags = r.hpos, g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;      // flags carries hpos through the staging only
                     stage[pos] = g;
                 }
                 lds_sync<MULTIWAVE>();
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
                     r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
                     r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
                     r.hpos = g.flags;
-                    r.conf = g.conf;
+                    r.conf = g.conf, r.vx = g.vx, r.vy = g.vy;
                 }
             }
         }
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
         g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
         g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
-        g.conf = r.conf, g.reserved = 0.0;
+        g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;
         rows[row] = g;
     }
     if (row == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;

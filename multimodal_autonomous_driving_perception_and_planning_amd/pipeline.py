@@ -122,6 +122,25 @@ class HotLoop:
         nat.check(self.L.av_maneuver_detect(self.ctx.handle, stream or self._s, self.S, self.W, nat.ptr(self.vstate),
                                             nat.ptr(lane_offset), nat.ptr(self.mv_state), nat.ptr(self.maneuver)))
 
+    def enqueue_interactions(self, stream=None, frame_shape=None, class_names=None):
+        """Interaction tags of every frame of the window from the tracker's snapshot tables and the Kalman output
+        (InteractionDetector.detect, interaction_detector.py:132-222); call where both are complete (after the
+        join).  Results: self.inter_rows (av_interaction_row [S][W][tcap]), self.inter_summary ([S][W])."""
+        from .perception.detector import ObjectDetector
+        from .tagging.interaction_detector import interaction_cfg
+        if self.tcap != 64 or self.snap is None:
+            raise RuntimeError("enqueue_interactions needs keep_snapshots=True and tcap 64")
+        if not hasattr(self, "inter_state"):
+            self.inter_state = torch.zeros(self.S * int(self.L.av_interaction_state_bytes(self.tcap)), dtype=torch.uint8,
+                                           device=self.dev)
+            nat.check(self.L.av_interaction_reset(self.ctx.handle, stream or self._s, self.S, self.tcap, nat.ptr(self.inter_state)))
+            self.inter_rows = torch.zeros(self.S, self.W, self.tcap, nat.INTERACTION_ROW_BYTES, dtype=torch.uint8, device=self.dev)
+            self.inter_summary = torch.zeros(self.S, self.W, nat.INTERACTION_SUMMARY_BYTES, dtype=torch.uint8, device=self.dev)
+        cfg = interaction_cfg(frame_shape or (self.h, self.w), class_names or [ObjectDetector.CLASSES[k] for k in range(8)])
+        nat.check(self.L.av_interaction_detect(self.ctx.handle, stream or self._s, C.byref(cfg), self.S, self.W, self.tcap,
+                                               nat.ptr(self.snap), nat.ptr(self.snap_n), nat.ptr(self.vstate), None, None,
+                                               nat.ptr(self.inter_state), nat.ptr(self.inter_rows), nat.ptr(self.inter_summary)))
+
     def enqueue_plan(self, stream=None):
         nat.check(self.L.av_planner_plan(self.ctx.handle, stream or self._s, self.S * self.W,
                                          nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),

@@ -1,4 +1,5 @@
 from multimodal_autonomous_driving_perception_and_planning_amd.tagging import (  # noqa: F401
-    LateralManeuver, LongitudinalManeuver, ManeuverDetector, ManeuverTags, TurningManeuver)
+    Interaction, InteractionDetector, InteractionTags, InteractionType, LateralManeuver, LongitudinalManeuver,
+    ManeuverDetector, ManeuverTags, RiskLevel, TurningManeuver)
 
-__all__ = ["ManeuverDetector"]
+__all__ = ["ManeuverDetector", "InteractionDetector"]

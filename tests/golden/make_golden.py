@@ -9,6 +9,7 @@ here do).  Importable reference stages:
   * src.tracking.MultiObjectTracker                            (multi_object_tracker.py:50-319)
   * src.planning.MotionPlanner                                 (motion_planner.py:57-374)
   * src/tagging/maneuver_detector.py ManeuverDetector          (loaded from its file; NumPy only)
+  * src/tagging/interaction_detector.py InteractionDetector    (loaded from its file; NumPy only)
 
 `cv2` is absent here; detector.py imports it at module level but the simulated
 path never touches it, so an empty module object is registered under that name
@@ -361,12 +362,168 @@ def golden_maneuver():
         len(states), np.bincount(idx[:, 0], minlength=4), np.bincount(idx[:, 1], minlength=5), np.bincount(idx[:, 2], minlength=6)))
 
 
+def golden_interaction(det_mod, trk_mod, dets):
+    """The reference chain detector -> tracker -> InteractionDetector on the 720p simulated detections, 300 frames,
+    ego speed varying around 10 m/s.  Recorded per frame: the summary fields, and per returned (confirmed) track in
+    tracker order the Interaction it produced (type -1 = none), plus the order of tags.interactions after the
+    reference's sort (agent ids), which decides primary_interaction."""
+    mod = _import_tagger("interaction_detector")
+    nfr = 300
+    n, box, cls, conf = dets["n_720"][:nfr], dets["box_720"][:nfr], dets["cls_720"][:nfr], dets["conf_720"][:nfr]
+    trk = trk_mod.MultiObjectTracker()
+    itd = mod.InteractionDetector()
+    types_ = [t for t in mod.InteractionType]
+    risks = [r for r in mod.RiskLevel]
+    speeds = 10.0 + 3.0 * np.sin(np.arange(nfr) * 0.05)
+    K = TMAX
+    out = dict(speed=speeds, n_tracks=np.zeros(nfr, np.int32), ids=np.full((nfr, K), -1, np.int32),
+               type=np.full((nfr, K), -1, np.int32), risk=np.zeros((nfr, K), np.int32), conf=np.zeros((nfr, K)),
+               dist=np.zeros((nfr, K)), rel=np.zeros((nfr, K)), ttc=np.full((nfr, K), np.nan),
+               counts=np.zeros((nfr, 4), np.int32), n_inter=np.zeros(nfr, np.int32), primary=np.full(nfr, -1, np.int32),
+               overall=np.zeros(nfr, np.int32), closest=np.zeros(nfr), min_ttc=np.full(nfr, np.nan), ts=np.zeros(nfr),
+               order=np.full((nfr, K), -1, np.int32))
+    for f in range(nfr):
+        d = [_Det(det_mod, box[f, j], cls[f, j], conf[f, j]).d for j in range(int(n[f]))]
+        tracks = trk.update(d)
+        vs = types.SimpleNamespace(speed=float(speeds[f]), x=0.0, y=0.0) if f != 77 else None     # one frame without state
+        # per-track records need the un-sorted association track -> interaction: replay _analyze on a spy
+        per = {}
+        orig = itd._analyze_interaction
+
+        def spy(track, *a, **k):
+            r = orig(track, *a, **k)
+            per[track.track_id] = r
+            return r
+
+        itd._analyze_interaction = spy
+        tags = itd.detect(tracks, vs, frame_shape=(720, 1280))
+        itd._analyze_interaction = orig
+        out["n_tracks"][f] = len(tracks)
+        for k, t in enumerate(tracks):
+            out["ids"][f, k] = t.track_id
+            r = per.get(t.track_id)
+            if r is not None:
+                out["type"][f, k] = types_.index(r.type)
+                out["risk"][f, k] = risks.index(r.risk_level)
+                out["conf"][f, k], out["dist"][f, k], out["rel"][f, k] = r.confidence, r.distance, r.relative_speed
+                out["ttc"][f, k] = np.nan if r.time_to_collision is None else r.time_to_collision
+        out["counts"][f] = (tags.agent_count, tags.pedestrian_count, tags.cyclist_count, tags.vehicle_count)
+        out["n_inter"][f] = len(tags.interactions)
+        out["primary"][f] = -1 if tags.primary_interaction is None else types_.index(tags.primary_interaction)
+        out["overall"][f] = risks.index(tags.overall_risk)
+        out["closest"][f] = tags.closest_agent_distance
+        out["min_ttc"][f] = np.nan if tags.min_ttc is None else tags.min_ttc
+        out["ts"][f] = tags.timestamp
+        for k, it in enumerate(tags.interactions):
+            out["order"][f, k] = it.agent_id
+    out["type_names"] = np.array([t.value for t in types_])
+    out["risk_names"] = np.array([r.value for r in risks])
+    np.savez_compressed(os.path.join(OUT, "interaction.npz"), **out)
+    tt = out["type"][out["type"] >= 0]
+    print("interaction.npz: %d frames; types seen %s; overall risk %s; cut-ins %d" % (
+        nfr, dict(zip(*np.unique(tt, return_counts=True))), np.bincount(out["overall"], minlength=4), int((tt == 4).sum())))
+
+
+def golden_interaction_synth():
+    """Handcrafted track lists through the real InteractionDetector.detect (default frame_shape 480x640): persistent
+    ids so histories build up, boxes big and low enough for NEAR_MISS, degenerate heights, velocity None, class names
+    outside the detector's list, frames with no tracks, tracks that disappear and slots that are re-used."""
+    mod = _import_tagger("interaction_detector")
+    itd = mod.InteractionDetector()
+    types_ = [t for t in mod.InteractionType]
+    risks = [r for r in mod.RiskLevel]
+    names = ["car", "truck", "pedestrian", "cyclist", "motorcycle", "bus", "traffic_light", "stop_sign", "bicycle", "person"]
+    rs = np.random.RandomState(5)
+    nfr, K = 160, 12
+    live = {}                       # slot -> dict(id, cls, x, y, w, h, dx)
+    next_id = 1
+    out = dict(n=np.zeros(nfr, np.int32), ids=np.full((nfr, K), -1, np.int32), slot=np.full((nfr, K), -1, np.int32),
+               box=np.zeros((nfr, K, 4), np.int32), cls=np.zeros((nfr, K), np.int32), tconf=np.zeros((nfr, K)),
+               vel=np.zeros((nfr, K, 2)), has_vel=np.zeros((nfr, K), np.int32), speed=np.zeros(nfr), has_state=np.ones(nfr, np.int32),
+               type=np.full((nfr, K), -1, np.int32), risk=np.zeros((nfr, K), np.int32), conf=np.zeros((nfr, K)),
+               dist=np.zeros((nfr, K)), rel=np.zeros((nfr, K)), ttc=np.full((nfr, K), np.nan),
+               counts=np.zeros((nfr, 4), np.int32), n_inter=np.zeros(nfr, np.int32), primary=np.full(nfr, -1, np.int32),
+               overall=np.zeros(nfr, np.int32), closest=np.zeros(nfr), min_ttc=np.full(nfr, np.nan), ts=np.zeros(nfr),
+               order=np.full((nfr, K), -1, np.int32))
+    for f in range(nfr):
+        # births / deaths
+        for s in list(live):
+            if rs.rand() < 0.04:
+                del live[s]
+        while len(live) < (0 if 60 <= f < 64 else rs.randint(3, K)):
+            free = [s for s in range(K) if s not in live]
+            if not free:
+                break
+            s = free[0]
+            live[s] = dict(id=next_id, cls=int(rs.randint(0, len(names))), x=float(rs.randint(0, 560)), y=float(rs.randint(150, 420)),
+                           w=int(rs.randint(20, 120)), h=int(rs.choice([0, -3, 20, 40, 80, 120, 200])), dx=float(rs.randint(-6, 7)), age=0)
+            next_id += 1
+        if 60 <= f < 64:
+            live.clear()
+        tracks = []
+        order_slots = sorted(live, key=lambda s: live[s]["id"])          # tracker order: ascending id
+        for s in order_slots:
+            t = live[s]
+            vy = float(rs.randint(-8, 9)) / 2.0
+            vel = None if t["age"] == 0 or rs.rand() < 0.1 else (t["dx"], vy)
+            t["x"] += t["dx"]
+            t["age"] += 1
+            x1, y1 = int(t["x"]), int(t["y"])
+            bbox = (x1, y1, x1 + t["w"], y1 + t["h"])
+            if 100 <= f < 135 and itd._estimate_distance(bbox, (480, 640)) < 3.0:
+                continue                      # slow stretch without near-misses: overall risk comes from the rules
+            tracks.append(types.SimpleNamespace(track_id=t["id"], class_name=names[t["cls"]], bbox=bbox, velocity=vel,
+                                                confidence=float(rs.uniform(0.3, 1.0)), _slot=s, _cls=t["cls"]))
+        speed = float(rs.uniform(0.0, 20.0)) if not 100 <= f < 135 else float(rs.uniform(0.0, 0.3))   # slow stretch: few TTCs
+        vs = None if f % 37 == 36 else types.SimpleNamespace(speed=speed, x=0.0, y=0.0)
+        out["speed"][f], out["has_state"][f] = speed, 0 if vs is None else 1
+        per = {}
+        orig = itd._analyze_interaction
+
+        def spy(track, *a, **k):
+            r = orig(track, *a, **k)
+            per[track.track_id] = r
+            return r
+
+        itd._analyze_interaction = spy
+        tags = itd.detect(tracks, vs)
+        itd._analyze_interaction = orig
+        out["n"][f] = len(tracks)
+        for k, t in enumerate(tracks):
+            out["ids"][f, k], out["slot"][f, k], out["box"][f, k], out["cls"][f, k] = t.track_id, t._slot, t.bbox, t._cls
+            out["tconf"][f, k] = t.confidence
+            if t.velocity is not None:
+                out["vel"][f, k], out["has_vel"][f, k] = t.velocity, 1
+            r = per.get(t.track_id)
+            if r is not None:
+                out["type"][f, k], out["risk"][f, k] = types_.index(r.type), risks.index(r.risk_level)
+                out["conf"][f, k], out["dist"][f, k], out["rel"][f, k] = r.confidence, r.distance, r.relative_speed
+                out["ttc"][f, k] = np.nan if r.time_to_collision is None else r.time_to_collision
+        out["counts"][f] = (tags.agent_count, tags.pedestrian_count, tags.cyclist_count, tags.vehicle_count)
+        out["n_inter"][f] = len(tags.interactions)
+        out["primary"][f] = -1 if tags.primary_interaction is None else types_.index(tags.primary_interaction)
+        out["overall"][f] = risks.index(tags.overall_risk)
+        out["closest"][f] = tags.closest_agent_distance
+        out["min_ttc"][f] = np.nan if tags.min_ttc is None else tags.min_ttc
+        out["ts"][f] = tags.timestamp
+        for k, it in enumerate(tags.interactions):
+            out["order"][f, k] = it.agent_id
+    out["class_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "interaction_synth.npz"), **out)
+    tt = out["type"][out["type"] >= 0]
+    print("interaction_synth.npz: %d frames; types seen %s; overall %s; primary %s" % (
+        nfr, dict(zip(*np.unique(tt, return_counts=True))), np.bincount(out["overall"], minlength=4),
+        dict(zip(*np.unique(out["primary"], return_counts=True)))))
+
+
 def main():
     det_mod, trk_mod, pln_mod = _import_reference()
     dets = golden_detections(det_mod)
     golden_tracker(det_mod, trk_mod, dets)
     golden_planner(pln_mod)
     golden_maneuver()
+    golden_interaction(det_mod, trk_mod, dets)
+    golden_interaction_synth()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print("%-24s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))

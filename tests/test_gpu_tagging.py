@@ -119,3 +119,186 @@ def test_hot_loop_maneuver_stage_matches_oracle(torch_gpu):
                 assert (r["lateral"], r["longitudinal"], r["turning"]) == idx, (k, s, f)
                 assert (r["lateral_confidence"], r["longitudinal_confidence"], r["turning_confidence"], r["speed_kmh"],
                         r["acceleration"], r["yaw_rate_deg"], r["timestamp"]) == val, (k, s, f)
+
+
+def _cmp_rows(o, g, f, k):
+    assert (o["type"], o["agent_id"]) == (g["type"][f, k], g["ids"][f, k]), (f, k, o)
+    if o["type"] >= 0:
+        assert (o["risk"], o["confidence"], o["distance"], o["relative_speed"]) == (g["risk"][f, k], g["conf"][f, k], g["dist"][f, k], g["rel"][f, k]), (f, k, o)
+        assert (np.isnan(o["ttc"]) and np.isnan(g["ttc"][f, k])) or o["ttc"] == g["ttc"][f, k], (f, k)
+
+
+def _cmp_summary(q, g, f, n):
+    if n:
+        assert (q["agent_count"], q["pedestrian_count"], q["cyclist_count"], q["vehicle_count"]) == tuple(g["counts"][f]), f
+        assert q["closest_distance"] == g["closest"][f], f
+    else:
+        assert q["agent_count"] == 0 and np.isinf(q["closest_distance"]), f
+    assert (q["n_interactions"], q["primary_type"], q["overall_risk"]) == (g["n_inter"][f], g["primary"][f], g["overall"][f]), (f, q)
+    assert q["timestamp"] == g["ts"][f], f
+    assert (np.isnan(q["min_ttc"]) and np.isnan(g["min_ttc"][f])) or q["min_ttc"] == g["min_ttc"][f], f
+
+
+@pytest.mark.parametrize("windows", [(160,), (1, 7, 50, 102)])
+def test_interaction_kernel_matches_reference_synth_golden(torch_gpu, golden, windows):
+    """Handcrafted track lists that went through the real InteractionDetector: every rule, None velocities, degenerate
+    boxes, slot re-use, empty frames, frames without a vehicle state -- bit for bit, across window splits."""
+    torch = torch_gpu
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.tagging.interaction_detector import class_kind, interaction_cfg
+    g = golden("interaction_synth")
+    names = list(g["class_names"])
+    ctx, L, st = nat.default_context(0), nat.lib(), nat.stream_handle()
+    N, tcap = len(g["n"]), 64
+    rows = np.zeros((N, tcap), nat.TRACK_ROW_FIELDS)
+    vy = np.zeros((N, tcap))
+    for f in range(N):
+        for k in range(int(g["n"][f])):
+            r = rows[f, k]
+            r["id"], r["slot"], r["cls"], r["flags"], r["conf"] = g["ids"][f, k], g["slot"][f, k], class_kind(names[g["cls"][f, k]]), 1, g["tconf"][f, k]
+            r["x1"], r["y1"], r["x2"], r["y2"] = g["box"][f, k]
+            r["hist_len"] = 2 if g["has_vel"][f, k] else 1
+            vy[f, k] = g["vel"][f, k, 1]
+    vstate = np.zeros((N, 12))
+    vstate[:, 5] = g["speed"]
+    state = torch.zeros(int(L.av_interaction_state_bytes(tcap)), dtype=torch.uint8, device="cuda")
+    nat.check(L.av_interaction_reset(ctx.handle, st, 1, tcap, nat.ptr(state)))
+    cfg = interaction_cfg((480, 640))
+    f0 = 0
+    for W in windows:
+        sl = slice(f0, f0 + W)
+        d_rows = torch.from_numpy(rows[sl].view(np.uint8).copy()).cuda()
+        d_n, d_vs = torch.as_tensor(g["n"][sl].astype(np.int32)).cuda(), torch.as_tensor(vstate[sl].copy()).cuda()
+        d_has, d_vy = torch.as_tensor(g["has_state"][sl].astype(np.uint8)).cuda(), torch.as_tensor(vy[sl].copy()).cuda()
+        out = torch.zeros(W * tcap * nat.INTERACTION_ROW_BYTES, dtype=torch.uint8, device="cuda")
+        summ = torch.zeros(W * nat.INTERACTION_SUMMARY_BYTES, dtype=torch.uint8, device="cuda")
+        nat.check(L.av_interaction_detect(ctx.handle, st, C.byref(cfg), 1, W, tcap, nat.ptr(d_rows), nat.ptr(d_n), nat.ptr(d_vs),
+                                          nat.ptr(d_has), nat.ptr(d_vy), nat.ptr(state), nat.ptr(out), nat.ptr(summ)))
+        o = out.cpu().numpy().view(nat.INTERACTION_ROW_FIELDS).reshape(W, tcap)
+        q = summ.cpu().numpy().view(nat.INTERACTION_SUMMARY_FIELDS)
+        for i in range(W):
+            f, n = f0 + i, int(g["n"][f0 + i])
+            for k in range(n):
+                _cmp_rows(o[i, k], g, f, k)
+            assert np.all(o[i, n:]["type"] == -1)
+            _cmp_summary(q[i], g, f, n)
+        f0 += W
+
+
+def test_interaction_end_to_end_matches_reference_chain(torch_gpu, golden):
+    """Simulated detector -> tracker -> interaction kernel, all on the device, against the reference's own chain
+    (detector.py -> multi_object_tracker.py -> interaction_detector.py) over 300 frames at 1280x720."""
+    torch = torch_gpu
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    from multimodal_autonomous_driving_perception_and_planning_amd.tagging.interaction_detector import interaction_cfg
+    from src.perception import ObjectDetector
+    g = golden("interaction")
+    W = len(g["speed"])
+    loop = HotLoop(n_streams=1, window=W, keep_waypoints=False)
+    loop.reset(frame_offsets=[0])
+    loop.enqueue_detect()
+    loop.enqueue_track()
+    loop.synchronize()
+    L, tcap = nat.lib(), loop.tcap
+    vstate = np.zeros((1, W, 12))
+    vstate[0, :, 5] = g["speed"]
+    has = np.ones((1, W), np.uint8)
+    has[0, 77] = 0
+    d_vs, d_has = torch.as_tensor(vstate).cuda(), torch.as_tensor(has).cuda()
+    state = torch.zeros(int(L.av_interaction_state_bytes(tcap)), dtype=torch.uint8, device="cuda")
+    nat.check(L.av_interaction_reset(loop.ctx.handle, loop._s, 1, tcap, nat.ptr(state)))
+    out = torch.zeros(W * tcap * nat.INTERACTION_ROW_BYTES, dtype=torch.uint8, device="cuda")
+    summ = torch.zeros(W * nat.INTERACTION_SUMMARY_BYTES, dtype=torch.uint8, device="cuda")
+    cfg = interaction_cfg((720, 1280), [ObjectDetector.CLASSES[k] for k in range(8)])
+    nat.check(L.av_interaction_detect(loop.ctx.handle, loop._s, C.byref(cfg), 1, W, tcap, nat.ptr(loop.snap), nat.ptr(loop.snap_n),
+                                      nat.ptr(d_vs), nat.ptr(d_has), None, nat.ptr(state), nat.ptr(out), nat.ptr(summ)))
+    loop.synchronize()
+    rows, cnt = loop.snapshots()
+    o = out.cpu().numpy().view(nat.INTERACTION_ROW_FIELDS).reshape(W, tcap)
+    q = summ.cpu().numpy().view(nat.INTERACTION_SUMMARY_FIELDS)
+    for f in range(W):
+        conf_rows = [k for k in range(cnt[0, f]) if rows[0, f]["flags"][k] & 1]
+        assert len(conf_rows) == g["n_tracks"][f], f
+        for j, k in enumerate(conf_rows):
+            _cmp_rows(o[f, k], g, f, j)
+        _cmp_summary(q[f], g, f, len(conf_rows))
+        if q[f]["primary_row"] >= 0:
+            assert o[f, q[f]["primary_row"]]["agent_id"] == g["order"][f, 0], f
+
+
+def test_interaction_detector_class(torch_gpu, golden):
+    import types
+    from src.tagging import InteractionDetector
+    from src.tagging.interaction_detector import InteractionTags, InteractionType, RiskLevel
+    g = golden("interaction_synth")
+    names = list(g["class_names"])
+    tnames, rnames = [t.value for t in InteractionType], [r.value for r in RiskLevel]
+    det = InteractionDetector()
+    for f in range(len(g["n"])):
+        n = int(g["n"][f])
+        tracks = [types.SimpleNamespace(track_id=int(g["ids"][f, k]), class_name=names[g["cls"][f, k]],
+                                        bbox=tuple(int(v) for v in g["box"][f, k]), confidence=float(g["tconf"][f, k]),
+                                        velocity=(tuple(g["vel"][f, k]) if g["has_vel"][f, k] else None)) for k in range(n)]
+        vs = types.SimpleNamespace(speed=float(g["speed"][f]), x=0.0, y=0.0) if g["has_state"][f] else None
+        t = det.detect(tracks, vs)
+        assert isinstance(t, InteractionTags) and t.timestamp == g["ts"][f], f
+        assert [i.agent_id for i in t.interactions] == list(g["order"][f][:g["n_inter"][f]]), f
+        assert (t.primary_interaction.value if t.primary_interaction else None) == (tnames[g["primary"][f]] if g["primary"][f] >= 0 else None), f
+        assert t.overall_risk.value == rnames[g["overall"][f]], f
+        if n:
+            assert (t.agent_count, t.pedestrian_count, t.cyclist_count, t.vehicle_count) == tuple(g["counts"][f]), f
+            assert t.closest_agent_distance == g["closest"][f], f
+        else:
+            assert t.agent_count == 0 and t.closest_agent_distance == float("inf")
+        assert (t.min_ttc is None and np.isnan(g["min_ttc"][f])) or t.min_ttc == g["min_ttc"][f], f
+        by_id = {int(g["ids"][f, k]): k for k in range(n)}
+        for i in t.interactions:
+            k = by_id[i.agent_id]
+            assert (i.type.value, i.risk_level.value, i.confidence, i.distance, i.relative_speed) == (
+                tnames[g["type"][f, k]], rnames[g["risk"][f, k]], g["conf"][f, k], g["dist"][f, k], g["rel"][f, k]), (f, k)
+            assert (i.time_to_collision is None and np.isnan(g["ttc"][f, k])) or i.time_to_collision == g["ttc"][f, k]
+            assert i.agent_class == names[g["cls"][f, k]]
+        assert isinstance(t.get_tags_list(), list) and isinstance(t.to_dict(), dict)
+    assert det.get_interaction_summary() == {"tracked_agents": len(set(g["ids"][g["ids"] >= 0])), "frame_count": len(g["n"])}
+    det.reset()
+    assert det.frame_count == 0 and det.get_interaction_summary()["tracked_agents"] == 0
+
+
+def test_hot_loop_interaction_stage(torch_gpu):
+    """HotLoop.enqueue_interactions over two consecutive windows == the oracle fed the tracker/KF outputs of the same loop."""
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    from oracle import interaction_ref as I
+    from src.perception import ObjectDetector
+    S, W = 2, 40
+    loop = HotLoop(n_streams=S, window=W, keep_waypoints=False)
+    loop.reset(frame_offsets=[0, 17])
+    refs = [I.InteractionRef() for _ in range(S)]
+    names = [ObjectDetector.CLASSES[k] for k in range(8)]
+    for k in range(2):
+        z = np.stack([np.asarray(generate_ego_motion(2 * W, seed=s))[k * W:(k + 1) * W] for s in range(S)])
+        loop.load_measurements(z)
+        loop.step(sync=True)
+        loop.enqueue_interactions()
+        loop.synchronize()
+        rows, cnt = loop.snapshots()
+        vs = loop.vstate.cpu().numpy()
+        o = loop.inter_rows.cpu().numpy().view(nat.INTERACTION_ROW_FIELDS).reshape(S, W, loop.tcap)
+        q = loop.inter_summary.cpu().numpy().view(nat.INTERACTION_SUMMARY_FIELDS).reshape(S, W)
+        for s in range(S):
+            for f in range(W):
+                r = rows[s, f]
+                idx = [i for i in range(cnt[s, f]) if r["flags"][i] & 1]
+                tr = [dict(id=int(r["id"][i]), kind=I.kind_of(names[r["cls"][i]]), bbox=(int(r["x1"][i]), int(r["y1"][i]), int(r["x2"][i]), int(r["y2"][i])),
+                           vel=((float(r["vx"][i]), float(r["vy"][i])) if r["hist_len"][i] >= 2 else None), conf=r["conf"][i]) for i in idx]
+                per, summ = refs[s].detect(tr, vs[s, f, 5], (720, 1280))
+                for j, i in enumerate(idx):
+                    want = per[j]
+                    assert o[s, f, i]["type"] == (-1 if want is None else want["type"]), (k, s, f, i)
+                    if want is not None:
+                        assert (o[s, f, i]["risk"], o[s, f, i]["confidence"], o[s, f, i]["distance"], o[s, f, i]["relative_speed"]) == (
+                            want["risk"], want["conf"], want["dist"], want["rel"]), (k, s, f, i)
+                assert (q[s, f]["n_interactions"], q[s, f]["primary_type"], q[s, f]["overall_risk"]) == (summ["n_inter"], summ["primary"], summ["overall"])
+                assert q[s, f]["timestamp"] == summ["ts"]

@@ -127,3 +127,51 @@ def test_maneuver_oracle_matches_reference(golden):
     assert list(g["turning_names"]) == list(M.TURNING)
     assert set(np.unique(idx[:, 0])) == {0, 1, 2, 3} and set(np.unique(idx[:, 1])) == {0, 1, 2, 3, 4}
     assert set(np.unique(idx[:, 2])) == {0, 1, 2, 3, 4, 5}
+
+
+def _check_interaction_frame(per, summ, g, f, n):
+    if n:
+        assert summ["counts"] == tuple(g["counts"][f]), f
+    for k in range(n):
+        r = per[k]
+        if r is None:
+            assert g["type"][f, k] == -1, (f, k)
+            continue
+        assert (r["type"], r["risk"]) == (g["type"][f, k], g["risk"][f, k]), (f, k)
+        assert (r["conf"], r["dist"], r["rel"]) == (g["conf"][f, k], g["dist"][f, k], g["rel"][f, k]), (f, k)
+        assert (r["ttc"] is None and np.isnan(g["ttc"][f, k])) or r["ttc"] == g["ttc"][f, k], (f, k)
+    assert (summ["n_inter"], summ["primary"], summ["overall"]) == (g["n_inter"][f], g["primary"][f], g["overall"][f]), f
+    assert summ["closest"] == g["closest"][f] and summ["ts"] == g["ts"][f], f
+    assert (summ["min_ttc"] is None and np.isnan(g["min_ttc"][f])) or summ["min_ttc"] == g["min_ttc"][f], f
+    assert summ["order"] == list(g["order"][f][:summ["n_inter"]]), f
+
+
+def test_interaction_oracle_matches_reference(golden):
+    """InteractionDetector through the real reference module: handcrafted track lists, and the reference chain
+    detector -> tracker -> InteractionDetector replayed with the detector / tracker oracles.  Bit-for-bit, including
+    the order the reference's string-keyed sort leaves the interactions in."""
+    from oracle import interaction_ref as I
+    from oracle.detector_ref import simulated_detections
+    from oracle.tracker_ref import TrackerRef
+    g = golden("interaction_synth")
+    names = list(g["class_names"])
+    ref = I.InteractionRef()
+    for f in range(len(g["n"])):
+        n = int(g["n"][f])
+        tr = [dict(id=int(g["ids"][f, k]), kind=I.kind_of(names[g["cls"][f, k]]), bbox=tuple(int(v) for v in g["box"][f, k]),
+                   vel=(tuple(g["vel"][f, k]) if g["has_vel"][f, k] else None), conf=g["tconf"][f, k]) for k in range(n)]
+        per, summ = ref.detect(tr, g["speed"][f] if g["has_state"][f] else 10.0)
+        _check_interaction_frame(per, summ, g, f, n)
+    assert {1, 4, 7, 8, 9} <= set(np.unique(g["type"])) and {0, 1, 3} <= set(np.unique(g["overall"]))
+    g = golden("interaction")
+    det_names = ["car", "truck", "pedestrian", "cyclist", "motorcycle", "bus", "traffic_light", "stop_sign"]
+    trk, ref = TrackerRef(), I.InteractionRef()
+    for f in range(len(g["speed"])):
+        n, box, cls, conf = simulated_detections(f + 1, 720, 1280)
+        trk.update(n, box, cls, conf)
+        tr = [dict(id=r["id"], kind=I.kind_of(det_names[r["cls"]]), bbox=r["bbox"], vel=(r["vel"][-1] if r["vel"] else None),
+                   conf=r["conf"]) for r in trk.rows if r["hits"] >= 3]
+        assert [t["id"] for t in tr] == list(g["ids"][f][:g["n_tracks"][f]]), f
+        per, summ = ref.detect(tr, g["speed"][f] if f != 77 else 10.0, (720, 1280))
+        _check_interaction_frame(per, summ, g, f, len(tr))
+    assert {1, 4, 6, 7, 8} <= set(np.unique(g["type"]))
