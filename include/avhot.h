@@ -300,7 +300,10 @@ typedef struct av_interaction_summary {
 } av_interaction_summary;            /* 56 bytes */
 size_t av_interaction_state_bytes(int tcap);
 int av_interaction_reset(av_ctx* ctx, av_stream_t stream, int n_streams, int tcap, void* state);
-/*   snap, snap_n   the tracker's per-frame tables (av_tracker_update), tcap == 64
+/*   snap, snap_n   the tracker's per-frame tables (av_tracker_update), tcap == 64.  Windows longer than 64 frames
+ *                  are evaluated as independent 64-frame chunks that rebuild the 30-deep histories from the 29
+ *                  frames before them; this relies on what the tracker guarantees -- a returned track is returned
+ *                  in every frame until it is deleted.  Tables without that property: windows of <= 64 frames.
  *   vstate         f64 [S][W][AV_VSTATE_DOUBLES] (ego speed = element 5); NULL = 10.0 (:166)
  *   has_state      u8 [S][W], 0 = vehicle_state was None for that frame; NULL = always given
  *   vy             f64 [S][W][tcap] image-space y velocity per row instead of the row's float vy; may be NULL

@@ -4,19 +4,25 @@
 //   _estimate_distance :224-248, _estimate_relative_speed :250-260, _calculate_ttc :262-268,
 //   _analyze_interaction :270-372, _calculate_overall_risk :374-395, sort at :214.
 //
-// Mapping: one wave per stream, lane = row of the tracker's snapshot table (tcap 64), frames sequential -- the
-// cut-in rule looks at the oldest and newest of the last 30 centre abscissae of a track, a ring that lives in
-// LDS for the whole window, indexed by the row's history slot (stable while the track lives; a changed id in
-// a slot means the slot was re-used and the ring restarts).  The next frame's rows are in flight while the
-// current frame is evaluated.  Per-track rules are element-wise; the frame summary is a handful of ballots and
+// Mapping: lane = row of the tracker's snapshot table (tcap 64).  The only state that crosses frames is, per
+// track, the ring of its last 30 centre abscissae (the cut-in rule looks at the oldest and the newest); it lives
+// in LDS indexed by the row's history slot (stable while the track lives; a changed id in a slot means the slot
+// was re-used and the ring restarts).  A confirmed track is returned in EVERY frame until it dies, so the ring at
+// frame f is a function of the snapshot tables of frames f-29..f alone: a wave owns a chunk of IC frames of one
+// stream and first replays the 29 frames before it (ring updates only), which makes the chunks independent --
+// the window is spread over W/IC waves instead of one 1.8-us-per-frame chain.  Chunk 0 starts from the carried
+// state, the last chunk leaves the next state in a scratch copy that a second launch moves into place (another
+// chunk may still be reading the old one).  The next frame's rows are in flight while a frame is evaluated.  Per-track rules are element-wise; the frame summary is a handful of ballots and
 // wave minima.  All arithmetic in the reference's operation order (Python float == IEEE double).
 #include "common.h"
 
 namespace {
 
 constexpr int IH = 30;                       // history_length (:126)
+constexpr int IC = 64;                       // frames per chunk
 
-__host__ __device__ inline size_t istate_bytes(int tcap) { return 16 + (size_t)tcap * (8 + IH * 8); }
+__host__ __device__ inline size_t ihalf_bytes(int tcap) { return 16 + (size_t)tcap * (8 + IH * 8); }
+__host__ __device__ inline size_t istate_bytes(int tcap) { return 2 * ihalf_bytes(tcap); }      // state | scratch
 
 __device__ __forceinline__ double wave_min_f64(double v) { return -wave_max(-v); }
 
@@ -27,24 +33,55 @@ __global__ void __launch_bounds__(64) interaction_kernel(av_interaction_cfg cfg,
                                                          av_interaction_row* __restrict__ rows, av_interaction_summary* __restrict__ summ) {
     __shared__ double ring[64][IH];
     __shared__ int hid[64], hcnt[64];
-    const int s = blockIdx.x, lane = threadIdx.x;
+    const int s = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int c0 = chunk * IC, c1 = (c0 + IC) < n_frames ? (c0 + IC) : n_frames;
     unsigned char* st = state_all + (size_t)s * istate_bytes(tcap);
-    long long* hdr = reinterpret_cast<long long*>(st);
-    int* g_id = reinterpret_cast<int*>(st + 16);
-    int* g_cnt = g_id + tcap;
-    double* g_ring = reinterpret_cast<double*>(st + 16 + (size_t)tcap * 8);
-    long long frame_count = hdr[0];
-    hid[lane] = g_id[lane], hcnt[lane] = g_cnt[lane];
-    for (int i = lane; i < 64 * IH; i += 64) ring[i / IH][i % IH] = g_ring[i];
+    const long long* hdr = reinterpret_cast<const long long*>(st);
+    const int* g_id = reinterpret_cast<const int*>(st + 16);
+    const int* g_cnt = g_id + tcap;
+    const double* g_ring = reinterpret_cast<const double*>(st + 16 + (size_t)tcap * 8);
+    const long long frame0 = hdr[0];
+    const av_track_row* sp = snap + (size_t)s * n_frames * tcap;
+    int r0 = c0 - (IH - 1);                       // first frame to replay
+    if (r0 <= 0) {                                // the carried state covers everything before the window
+        r0 = 0;
+        hid[lane] = g_id[lane], hcnt[lane] = g_cnt[lane];
+        for (int i = lane; i < 64 * IH; i += 64) ring[i / IH][i % IH] = g_ring[i];
+    } else {
+        hid[lane] = -1, hcnt[lane] = 0;
+    }
     __syncthreads();
+    // append this frame's centre to the track's ring; returns the length of its history
+    auto append = [&](const av_track_row& g, bool on, double cx, double& start_x) -> int {
+        if (!on) return 0;
+        const int slot = g.slot & 63;
+        int c = hid[slot] == g.id ? hcnt[slot] : 0;
+        ring[slot][c % IH] = cx;
+        c += 1;
+        hid[slot] = g.id, hcnt[slot] = c;
+        start_x = c <= IH ? ring[slot][0] : ring[slot][c % IH];
+        return c < IH ? c : IH;
+    };
+    auto lds_order = [&]() {                       // one wave: order its LDS writes before the next frame's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    };
+    av_track_row cur = sp[(size_t)r0 * tcap + lane];
+    for (int f = r0; f < c0; ++f) {               // replay: history only
+        const av_track_row g = cur;
+        cur = sp[(size_t)(f + 1) * tcap + lane];   // f + 1 <= c0 < n_frames
+        const bool on = lane < snap_n[(size_t)s * n_frames + f] && (g.flags & 1);
+        double sx;
+        append(g, on, (double)(g.x1 + g.x2) / 2, sx);
+        lds_order();
+    }
     const double w = (double)cfg.frame_w, h = (double)cfg.frame_h;
     const double w2 = w / 2, w4 = w / 4, w34 = 3 * w / 4;          // cfg.frame_w is an int: w/2 etc. as Python forms them
-    const av_track_row* sp = snap + (size_t)s * n_frames * tcap;
-    av_track_row cur = sp[lane];
-    for (int f = 0; f < n_frames; ++f) {
+    for (int f = c0; f < c1; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
         const av_track_row g = cur;
-        if (f + 1 < n_frames) cur = sp[(size_t)(f + 1) * tcap + lane];        // prefetch
+        if (f + 1 < c1) cur = sp[(size_t)(f + 1) * tcap + lane];              // prefetch
         const int n = snap_n[sf];
         const bool on = lane < n && (g.flags & 1);                             // a track the tracker returned
         const bool given = has_state ? has_state[sf] != 0 : true;
@@ -66,17 +103,8 @@ __global__ void __launch_bounds__(64) interaction_kernel(av_interaction_cfg cfg,
         const double ttc = has_ttc ? dist / rel : 0.0;
         const double cx = (double)(g.x1 + g.x2) / 2;
         // history: append, then the oldest / newest of the last IH entries
-        int hl = 0;
         double start_x = cx;
-        if (on) {
-            const int slot = g.slot & 63;
-            int c = hid[slot] == g.id ? hcnt[slot] : 0;
-            ring[slot][c % IH] = cx;
-            c += 1;
-            hid[slot] = g.id, hcnt[slot] = c;
-            hl = c < IH ? c : IH;
-            start_x = c <= IH ? ring[slot][0] : ring[slot][c % IH];
-        }
+        const int hl = append(g, on, cx, start_x);
         int type = -1, risk = 0;
         double conf = 0.0, o_rel = rel, o_ttc = has_ttc ? ttc : __builtin_nan("");
         if (on) {
@@ -113,7 +141,7 @@ __global__ void __launch_bounds__(64) interaction_kernel(av_interaction_cfg cfg,
         const unsigned long long m_int = __ballot(type >= 0);
         q.n_interactions = __popcll(m_int);
         q.primary_type = -1, q.primary_row = -1, q.overall_risk = 0;
-        q.timestamp = (double)frame_count / 30.0;
+        q.timestamp = (double)(frame0 + f) / 30.0;
         if (n_on == 0) {
             q.closest_distance = __builtin_inf(), q.min_ttc = __builtin_nan("");      // untouched defaults (:143-151)
         } else {
@@ -144,16 +172,28 @@ __global__ void __launch_bounds__(64) interaction_kernel(av_interaction_cfg cfg,
             }
         }
         if (lane == 0) summ[sf] = q;
-        frame_count += 1;
-        // one wave: its LDS writes above are ordered before the next frame's reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        lds_order();
     }
+    if (c1 != n_frames) return;
+    // last chunk: the state the next window starts from, into the scratch half
     __syncthreads();
-    g_id[lane] = hid[lane], g_cnt[lane] = hcnt[lane];
-    for (int i = lane; i < 64 * IH; i += 64) g_ring[i] = ring[i / IH][i % IH];
-    if (lane == 0) hdr[0] = frame_count;
+    unsigned char* sc = st + ihalf_bytes(tcap);
+    int* o_id = reinterpret_cast<int*>(sc + 16);
+    int* o_cnt = o_id + tcap;
+    double* o_ring = reinterpret_cast<double*>(sc + 16 + (size_t)tcap * 8);
+    o_id[lane] = hid[lane], o_cnt[lane] = hcnt[lane];
+    for (int i = lane; i < 64 * IH; i += 64) o_ring[i] = ring[i / IH][i % IH];
+    if (lane == 0) reinterpret_cast<long long*>(sc)[0] = frame0 + n_frames;
+}
+
+// scratch half -> state half (after every chunk of the window is done: stream order)
+__global__ void interaction_commit_kernel(int n_streams, int tcap, unsigned char* state) {
+    const size_t half8 = ihalf_bytes(tcap) / 8;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_streams * half8) return;
+    const size_t s = i / half8, k = i - s * half8;
+    long long* p = reinterpret_cast<long long*>(state + s * istate_bytes(tcap));
+    p[k] = p[half8 + k];
 }
 
 __global__ void interaction_reset_kernel(size_t n8, long long* state) {
@@ -194,8 +234,12 @@ int av_interaction_detect(av_ctx* ctx, av_stream_t stream, const av_interaction_
     AV_REQUIRE(n_streams > 0 && n_frames > 0, AV_EINVAL, "av_interaction_detect: n_streams/n_frames must be > 0");
     AV_REQUIRE(tcap == 64, AV_EINVAL, "av_interaction_detect: tcap %d not supported (64 only)", tcap);
     AV_REQUIRE(cfg->frame_h > 0 && cfg->frame_w > 0, AV_EINVAL, "av_interaction_detect: bad frame shape");
-    hipLaunchKernelGGL(interaction_kernel, dim3(n_streams), dim3(64), 0, as_stream(stream), *cfg, n_frames, tcap, snap, snap_n,
-                       vstate, has_state, vy, (unsigned char*)state, rows, summary);
+    hipLaunchKernelGGL(interaction_kernel, dim3((n_frames + IC - 1) / IC, n_streams), dim3(64), 0, as_stream(stream), *cfg,
+                       n_frames, tcap, snap, snap_n, vstate, has_state, vy, (unsigned char*)state, rows, summary);
+    AV_LAUNCH_CHECK();
+    const size_t n8 = (size_t)n_streams * ihalf_bytes(tcap) / 8;
+    hipLaunchKernelGGL(interaction_commit_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, as_stream(stream), n_streams,
+                       tcap, (unsigned char*)state);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--window", type=int, default=256)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--tcap", type=int, default=64)
-    ap.add_argument("--stages", default="detect,track,kf,plan")
+    ap.add_argument("--stages", default="detect,track,kf,plan")   # also: maneuver, interact
     ap.add_argument("--no-wp", action="store_true", help="planner: costs/order only (no waypoint stores)")
     a = ap.parse_args()
     S, W = a.streams, a.window
@@ -49,7 +49,7 @@ def main():
     F = S * W
     for name in a.stages.split(","):
         fn = {"detect": loop.enqueue_detect, "track": loop.enqueue_track, "kf": loop.enqueue_kf,
-              "plan": loop.enqueue_plan}[name]
+              "plan": loop.enqueue_plan, "maneuver": loop.enqueue_maneuver, "interact": loop.enqueue_interactions}[name]
         best, avg = timeit(loop, fn, a.reps)
         line = "%-7s S=%d W=%d  best %.4f ms  avg %.4f ms  %.3f us/frame-step  %.2f Mframes/s" % (
             name, S, W, best, avg, best * 1e3 / W, F / best / 1e3)
