@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--taggers", action="store_true",
+                    help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
     return ap.parse_args()
 
 
@@ -178,10 +180,14 @@ def main():
             loop.enqueue_plan()
             if timed:
                 nat.check(L.av_event_record(evs[k][1], s))
+            if a.taggers:
+                loop.enqueue_maneuver()                   # consumes the Kalman output (main stream)
             # the two chains share no buffer, so they only have to meet when somebody reads across them: per step
-            # for the track-table exchange, otherwise once before the final synchronisation
-            if xchg is not None:
+            # for the track-table exchange or the interaction tagger, otherwise once before the final synchronisation
+            if xchg is not None or a.taggers:
                 nat.check(L.av_join(h, s))
+            if a.taggers:
+                loop.enqueue_interactions()               # consumes the tracker's tables and the Kalman output
         if xchg is not None:
             xchg.exchange()
 
@@ -245,7 +251,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window, 1280x720, simulated detection + IoU "
                                    "tracker + 6-state KF + 21-candidate planner" % (a.workload, S, W),
-                       "streams_per_gpu": S, "window": W, "graph": bool(a.graph),
+                       "streams_per_gpu": S, "window": W, "graph": bool(a.graph), "taggers": bool(a.taggers),
                        "allgather_track_tables": bool(xchg is not None), "parallelism": "stream-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "planner_wave_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
