@@ -110,7 +110,7 @@ def bench_config3(a, world, rank, local):
                "config": {"workload": "config3: %d camera streams/GPU, 1280x720, YOLO-mode detector (random-init YOLOv8n "
                                       "topology, letterbox 384x640) + Canny/Hough lane detector" % S,
                           "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
-               "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (63 launches per forward, timed with decode+NMS)",
+               "roofline": {"bound": "mfma", "kernel": "conv_lds_kernel / conv_mfma_kernel (63 launches per forward; timed with preprocess, decode and NMS, beside the lane chain)",
                             "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                             "flops_per_launch": int(loop.flops_per_frame * S), "avg_launch_ms": round(det_ms, 4)}}
