@@ -50,21 +50,6 @@ __device__ __forceinline__ double iou_f64(int ax1, int ay1, int ax2, int ay2, in
     return uni > 0 ? (double)inter / (double)uni : 0.0;
 }
 
-// Same value through float64: every factor is an int32 converted exactly, every product/sum stays an
-// exact integer below 2^53 for coordinates |x| < 2^25, so inter/uni is the identical correctly rounded
-// quotient -- at a fraction of the int64 instruction count.
-__device__ __forceinline__ double iou_fast(int ax1, int ay1, int ax2, int ay2, double a1, int bx1, int by1, int bx2,
-                                           int by2) {
-    const int xi1 = ax1 > bx1 ? ax1 : bx1, yi1 = ay1 > by1 ? ay1 : by1;
-    const int xi2 = ax2 < bx2 ? ax2 : bx2, yi2 = ay2 < by2 ? ay2 : by2;
-    const int iw = xi2 - xi1, ih = yi2 - yi1;
-    if (iw <= 0 || ih <= 0) return 0.0;
-    const double inter = (double)iw * (double)ih;
-    const double a2 = (double)(bx2 - bx1) * (double)(by2 - by1);
-    const double uni = a1 + a2 - inter;
-    return uni > 0.0 ? inter / uni : 0.0;
-}
-
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     for (int i = 0; i < n; ++i) m &= m - 1;
     return __ffsll((long long)m) - 1;
