@@ -275,12 +275,11 @@ __device__ __forceinline__ void axis_predict(Axis& a, double dt, double h, doubl
     a.p[0][0] += q, a.p[1][1] += q, a.p[2][2] += q * 10.0;
 }
 
-__device__ __forceinline__ void axis_update(Axis& a, double zp, double zv, double rr) {
+__device__ __forceinline__ void axis_update(Axis& a, double zp, double zv, double rr, double (&K)[3][2]) {
     const double y0 = zp - a.x0, y1 = zv - a.x1;
     const double s00 = a.p[0][0] + rr, s01 = a.p[0][1], s10 = a.p[1][0], s11 = a.p[1][1] + rr;
     const double rdet = 1.0 / (s00 * s11 - s01 * s10);
     const double i00 = s11 * rdet, i01 = -s01 * rdet, i10 = -s10 * rdet, i11 = s00 * rdet;
-    double K[3][2];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         K[r][0] = a.p[r][0] * i00 + a.p[r][1] * i10;
@@ -346,6 +345,12 @@ __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.p[r][c] = st[6 + (2 * r + ax) * 6 + (2 * c + ax)];
     double carry_h = st[42], carry_sp = st[43], time = st[44];
+    double pp[3][3], Kc[3][2] = {{0, 0}, {0, 0}, {0, 0}};          // previous posterior P; gain of the last full update
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp[r][c] = a.p[r][c];
+    bool steady = false;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     const double dt = cfg.dt, h = 0.5 * (dt * dt), q = cfg.process_noise, rr = cfg.measurement_noise;
 
@@ -369,12 +374,33 @@ __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames
             const int m = ml[fb];
             const double zp = zl[fb][ax], zv = zl[fb][2 + ax];
             double vpred = a.x1;
-            if (m != 3) {
-                axis_predict(a, dt, h, q);
+            if (steady && m == 1) {
+                // The covariance recursion does not see the measurements.  Once a predict+update frame has
+                // reproduced the previous posterior P bit for bit, every further predict+update frame computes
+                // the same prior, gain and posterior again: only the state moves (same expressions as below).
+                const double nx0 = a.x0 + dt * a.x1 + h * a.x2;
+                const double nx1 = a.x1 + dt * a.x2;
+                a.x0 = nx0, a.x1 = nx1;
                 time += dt;
                 vpred = a.x1;
+                const double y0 = zp - a.x0, y1 = zv - a.x1;
+                a.x0 = a.x0 + (Kc[0][0] * y0 + Kc[0][1] * y1);
+                a.x1 = a.x1 + (Kc[1][0] * y0 + Kc[1][1] * y1);
+                a.x2 = a.x2 + (Kc[2][0] * y0 + Kc[2][1] * y1);
+            } else {
+                if (m != 3) {
+                    axis_predict(a, dt, h, q);
+                    time += dt;
+                    vpred = a.x1;
+                }
+                if (m == 1 || m == 3) axis_update(a, zp, zv, rr, Kc);
+                bool same = m == 1;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) same = same && a.p[r][c] == pp[r][c], pp[r][c] = a.p[r][c];
+                steady = __ballot(same) == ~0ull;            // every lane mirrors one of the two axes
             }
-            if (m == 1 || m == 3) axis_update(a, zp, zv, rr);
             if (lane < 2) {
                 double* w = raw[fb];
                 w[ax] = a.x0, w[2 + ax] = a.x1, w[4 + ax] = vpred;
