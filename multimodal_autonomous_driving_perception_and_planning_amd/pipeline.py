@@ -232,7 +232,8 @@ class PerceptionLoop:
         self.yolo = YoloV8n(model, device=device, batch=n_streams)
         self.ctx = self.yolo._dev.ctx
         self.yolo._prepare(h, w)
-        self.stream = torch.cuda.Stream(device=self.dev)
+        # the detector chain is the critical path when the lane chain runs beside it: higher queue priority
+        self.stream = torch.cuda.Stream(device=self.dev, priority=-1)
         S, d = n_streams, self.dev
         self.frames = torch.empty(S, h, w, 3, dtype=torch.uint8, device=d)
         self.ws = torch.empty(int(self.L.av_lane_workspace_bytes(S, h, w, max_segments)), dtype=torch.uint8, device=d)
