@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
                                                    const unsigned* __restrict__ nz_all, const int* __restrict__ npts,
                                                    int* __restrict__ accum_all, const float* __restrict__ trig,
                                                    int* __restrict__ segs, int* __restrict__ nseg,
-                                                   int* __restrict__ fallback) {
+                                                   int* __restrict__ fallback, int check_flag) {
     __shared__ unsigned nz[NZCAP];
     __shared__ unsigned bm[BMWORDS];
     __shared__ int fifo[FIFO];             // points drawn from the list but not voted yet (ring buffer)
@@ -956,6 +956,7 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
+    if (check_flag && fallback[s] == 0) return;                 // already done by houghp_shard
     const int total = npts[s];
     const int ymin = total > 0 ? (int)(nzg[0] >> 16) : 0, ymax = total > 0 ? (int)(nzg[total - 1] >> 16) : 0;
     const int wpr = (w + 31) >> 5;
@@ -1246,6 +1247,358 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
     if (tid == 0) nseg[s] = nlines;
 }
 
+// ---- L4b': PPHT with theta sharded over HG workgroups per frame, accumulator in LDS ------------------------------
+// houghp_fast is bound by its CU's L1/TA pipeline: every theta lane votes into its own 16-KB row of a global
+// accumulator, one cache line per lane per vote.  Here a frame is handled by HG single-wave workgroups; workgroup
+// g owns theta = HG*lane + g and keeps ONLY those rows, in LDS, over the rho range the points' bounding box can
+// reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed two to a word (PPHT's erase also
+// decrements pixels that have not voted yet, so counts go negative; |count| <= number of points <= 4096).  Every
+// workgroup replays the same point list, RNG, FIFO, bitmap and line walks -- all deterministic -- so they stay
+// in step by construction and exchange just two words per batch through global memory: the mask of batch points
+// whose vote reached the threshold, and, when a line fires, their best (count, theta) key.  A word carries its
+// batch sequence number and is stored/loaded with agent scope (the XCDs' L2s are not coherent); slots are double-
+// buffered by sequence parity; every spin is bounded and a timeout hands the frame to houghp_fast.
+constexpr int HG = 4;
+constexpr int HS_NZ = 4096, HS_BMW = 11776, HS_ACCW = 24576;      // LDS capacities: points, bitmap words, accumulator words
+constexpr unsigned HS_BIAS = 0x4000u;
+constexpr int HS_SPIN = 1 << 20;
+
+__global__ void hough_prep_kernel(int n_streams, int numrho, int* __restrict__ accum_all, int* __restrict__ fallback) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_streams * 32) return;
+    const int s = i >> 5, k = i & 31;
+    accum_all[(size_t)s * NUMANGLE * numrho + k] = 0;              // 16 exchange words (8 bytes each)
+    if (k == 0) fallback[s] = 0;
+}
+
+__global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
+                                                   const int* __restrict__ npts, int* __restrict__ accum_all,
+                                                   const float* __restrict__ trig, int* __restrict__ segs,
+                                                   int* __restrict__ nseg, int* __restrict__ fallback) {
+    __shared__ unsigned acc[HS_ACCW];
+    __shared__ unsigned nz[HS_NZ];
+    __shared__ unsigned bm[HS_BMW];
+    __shared__ int fifo[FIFO];
+    __shared__ int bpt[HB];
+    __shared__ int didx[HB];
+    __shared__ int row_sz[64];
+    __shared__ int sh_nb, sh_head, sh_tail, sh_count;
+    const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x;
+    const unsigned* nzg = nz_all + (size_t)s * h * w;
+    unsigned long long* xw = reinterpret_cast<unsigned long long*>(accum_all + (size_t)s * NUMANGLE * numrho);
+    const int total = npts[s];
+    const int ymin = total > 0 ? (int)(nzg[0] >> 16) : 0, ymax = total > 0 ? (int)(nzg[total - 1] >> 16) : 0;
+    const int wpr = (w + 31) >> 5;
+    auto give_up = [&]() {
+        if (lane == 0) fallback[s] = 1;
+    };
+    auto lds_order = [&]() {                       // one wave: order its LDS writes before later reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    };
+    if (total > HS_NZ || (ymax - ymin + 1) * wpr > HS_BMW || cfg.line_gap < 1) {        // same verdict in all HG workgroups
+        give_up();
+        return;
+    }
+    if (lane == 0) sh_head = 0, sh_tail = 0, sh_count = total;
+    for (int i = lane; i < (ymax - ymin + 1) * wpr; i += 64) bm[i] = 0;
+    lds_order();
+    int xmn = w, xmx = 0;
+    for (int i = lane; i < total; i += 64) {
+        const unsigned p = nzg[i];
+        nz[i] = p;
+        const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+        atomicOr(&bm[(y - ymin) * wpr + (x >> 5)], 1u << (x & 31));
+        xmn = x < xmn ? x : xmn, xmx = x > xmx ? x : xmx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int a = __shfl_xor(xmn, off, 64), b = __shfl_xor(xmx, off, 64);
+        xmn = a < xmn ? a : xmn, xmx = b > xmx ? b : xmx;
+    }
+    lds_order();
+    auto live = [&](int x, int y) -> bool {
+        return y >= ymin && y <= ymax && x >= 0 && x < w && ((bm[(y - ymin) * wpr + (x >> 5)] >> (x & 31)) & 1u);
+    };
+    const int th = lane * HG + g;
+    const bool th_on = th < NUMANGLE;
+    const float ct = th_on ? trig[2 * th] : 0.f, sn = th_on ? trig[2 * th + 1] : 0.f;
+    // this lane's accumulator row: the rho range of the points' bounding box for its theta (+-2 bins).  The
+    // capacity verdict has to be the same in all HG workgroups of the frame, so each one sizes every theta subset.
+    int my_lo = 0, my_base = 0;
+    {
+        const int half = (numrho - 1) / 2;
+        int my_tot = 0;
+        bool too_big = false;
+        for (int gg = 0; gg < HG; ++gg) {
+            const int t2 = lane * HG + gg;
+            int lo = 0, hi = -1;
+            if (t2 < NUMANGLE) {
+                const float c2 = trig[2 * t2], s2 = trig[2 * t2 + 1];
+                const float r0 = (float)xmn * c2 + (float)ymin * s2, r1 = (float)xmn * c2 + (float)ymax * s2;
+                const float r2 = (float)xmx * c2 + (float)ymin * s2, r3 = (float)xmx * c2 + (float)ymax * s2;
+                lo = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
+                hi = __float2int_rn(fmaxf(fmaxf(r0, r1), fmaxf(r2, r3))) + 2;
+                lo = lo < -half ? -half : lo, hi = hi > half ? half : hi;
+            }
+            lds_order();
+            row_sz[lane] = hi - lo + 1;
+            lds_order();
+            int tot = 0, base = 0;
+            for (int n = 0; n < 64; ++n) {
+                if (n == lane) base = tot;
+                tot += row_sz[n];
+            }
+            too_big = too_big || tot > 2 * HS_ACCW;
+            if (gg == g) my_lo = lo, my_base = base, my_tot = tot;
+        }
+        if (too_big) {
+            give_up();
+            return;
+        }
+        if (!th_on) my_lo = 0, my_base = 0;            // idle lanes read cell 0 (they add 0)
+        for (int i = lane; i < (my_tot + 1) / 2; i += 64) acc[i] = HS_BIAS | (HS_BIAS << 16);
+        lds_order();
+    }
+    auto cell = [&](int r, int& sh) -> unsigned* {
+        const int B = my_base + (r - my_lo);
+        sh = (B & 1) * 16;
+        return &acc[B >> 1];
+    };
+    auto vote = [&](int r, unsigned add) -> int {          // count BEFORE the vote (add = 0: a plain read)
+        int sh;
+        unsigned* p = cell(r, sh);
+        const unsigned old = atomicAdd(p, add << sh);
+        return (int)((old >> sh) & 0xFFFFu) - (int)HS_BIAS;
+    };
+    auto unvote = [&](int r) {
+        int sh;
+        unsigned* p = cell(r, sh);
+        atomicSub(p, 1u << sh);
+    };
+    auto rho = [&](int x, int y) { return th_on ? __float2int_rn((float)x * ct + (float)y * sn) : my_lo; };
+    // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope
+    unsigned seq = 0;
+    auto exchange = [&](int round, unsigned payload, unsigned (&got)[HG]) -> bool {
+        unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
+        unsigned long long wv = ((unsigned long long)seq << 32) | payload;
+        if (lane == 0) __hip_atomic_store(slot + g, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        if (lane < HG && lane != g) {
+            int it = 0;
+            for (;;) {
+                wv = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(wv >> 32) == seq) break;
+                if (++it > HS_SPIN) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (__ballot(!ok) != 0ull) return false;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) got[k] = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wv, k);
+        return true;
+    };
+    unsigned long long rng = ~0ull;
+    int nlines = 0;
+    const int shift = 16;
+    auto top_up = [&]() {
+        const int cnt = sh_count, fill = sh_tail - sh_head;
+        int nd = FIFO - HB - fill;
+        nd = nd < HB ? nd : HB;
+        nd = nd < cnt ? nd : cnt;
+        if (nd <= 0) return;
+        unsigned r_mine = 0;
+        for (int k = 0; k < nd; ++k) {
+            rng = (unsigned long long)(unsigned)rng * 4164903690ull + (unsigned)(rng >> 32);
+            if (k == lane) r_mine = (unsigned)rng;
+        }
+        if (lane < nd) didx[lane] = (int)(r_mine % (unsigned)(cnt - lane));
+        lds_order();
+        if (lane == 0) {
+            const int tail = sh_tail;
+            for (int k = 0; k < nd; ++k) {
+                const int idx = didx[k];
+                fifo[(tail + k) & (FIFO - 1)] = (int)nz[idx];
+                nz[idx] = nz[cnt - 1 - k];
+            }
+            sh_tail = tail + nd, sh_count = cnt - nd;
+        }
+        lds_order();
+    };
+    top_up();
+    for (;;) {
+        // ---- form the batch: pop up to HB points that are still live ---------------------------------------------
+        {
+            int head = sh_head;
+            int nb = 0;
+            for (;;) {
+                const int avail = sh_tail - head;
+                if (avail == 0) {
+                    if (sh_count == 0) break;
+                    if (lane == 0) sh_head = head;
+                    lds_order();
+                    top_up();
+                    continue;
+                }
+                const int take = avail < (HB - nb) ? avail : (HB - nb);
+                int p = 0;
+                bool ok = false;
+                if (lane < take) {
+                    p = fifo[(head + lane) & (FIFO - 1)];
+                    ok = live(p & 0xffff, p >> 16);
+                }
+                const unsigned long long okb = __ballot(ok);
+                if (ok) bpt[nb + __popcll(okb & ((1ull << lane) - 1ull))] = p;
+                nb += __popcll(okb);
+                head += take;
+                if (nb == HB) break;
+            }
+            if (lane == 0) sh_head = head, sh_nb = nb;
+            lds_order();
+        }
+        const int nb = sh_nb;
+        if (nb == 0) break;
+        // ---- speculative votes (LDS returning atomics, in order per lane) ---------------------------------------
+        int val[HB], pts[HB];
+#pragma unroll
+        for (int b = 0; b < HB; ++b) pts[b] = bpt[b < nb ? b : 0];
+#pragma unroll
+        for (int b = 0; b < HB; ++b) val[b] = vote(rho(pts[b] & 0xffff, pts[b] >> 16), (b < nb && th_on) ? 1u : 0u);
+        top_up();
+        unsigned hitbits = 0;
+#pragma unroll
+        for (int b = 0; b < HB; ++b) {
+            val[b] = (b < nb && th_on) ? val[b] + 1 : 0;
+            if (__ballot(val[b] >= cfg.threshold && b < nb && th_on) != 0ull) hitbits |= 1u << b;
+        }
+        seq += 1;
+        unsigned got[HG];
+        if (!exchange(0, hitbits, got)) {
+            give_up();
+            return;
+        }
+        unsigned hits = 0;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) hits |= got[k];
+        if (hits == 0) continue;
+        const int bs = __ffs((int)hits) - 1;
+        int kv = 0;
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+            if (b == bs) kv = val[b];
+        // counts can be negative (pixels erased before they voted): order-preserving signed -> unsigned map, 0 = no theta here
+        const unsigned mykey = th_on ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
+        const unsigned lbest = wave_max_u32(mykey);
+        // the votes of the points after bs are withdrawn; they are re-examined after the line is erased
+#pragma unroll
+        for (int b = 0; b < HB; ++b)
+            if (b > bs && b < nb && th_on) unvote(rho(bpt[b] & 0xffff, bpt[b] >> 16));
+        if (!exchange(1, lbest, got)) {
+            give_up();
+            return;
+        }
+        unsigned best = 0;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) best = got[k] > best ? got[k] : best;
+        best ^= 0x80000000u;
+        if (lane == 0) {
+            int head = sh_head;
+            for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
+            sh_head = head;
+        }
+        lds_order();
+        const int max_n = 255 - (int)(best & 255u);
+        const int j = bpt[bs] & 0xffff, i = bpt[bs] >> 16;
+        // ---- walk along the line in both directions --------------------------------------------------------------
+        const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
+        int x0 = j, y0 = i, dx0, dy0, xflag;
+        if (fabsf(a) > fabsf(b)) {
+            xflag = 1;
+            dx0 = a > 0 ? 1 : -1;
+            dy0 = __float2int_rn(b * (float)(1 << shift) / fabsf(a));
+            y0 = (y0 << shift) + (1 << (shift - 1));
+        } else {
+            xflag = 0;
+            dy0 = b > 0 ? 1 : -1;
+            dx0 = __float2int_rn(a * (float)(1 << shift) / fabsf(b));
+            x0 = (x0 << shift) + (1 << (shift - 1));
+        }
+        int ends[2][3];
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            int gap = 0, et = 0;
+            bool done = false;
+            for (int t0 = 0; !done; t0 += 64) {
+                const int t = t0 + lane;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                const bool on = inb && live(j1, i1);
+                const unsigned long long fo = __ballot(on), fi = __ballot(inb);
+                const int nin = fi == ~0ull ? 64 : __ffsll((long long)~fi) - 1;         // in-bounds steps of this word
+                int pos = 0;
+                while (pos < nin) {                                                        // the gap rule (line_gap >= 1)
+                    const unsigned long long rest = fo >> pos;
+                    int z = rest == 0ull ? 64 : __ffsll((long long)rest) - 1;            // zeros before the next hit
+                    if (z >= nin - pos) {
+                        const int zeros = nin - pos;
+                        if (gap + zeros > cfg.line_gap) done = true;
+                        gap += zeros;
+                        pos = nin;
+                        break;
+                    }
+                    if (gap + z > cfg.line_gap) { done = true; break; }
+                    pos += z;
+                    gap = 0;
+                    et = t0 + pos;
+                    ++pos;
+                }
+                if (nin < 64) done = true;                                                 // left the image
+            }
+            const int xx = x0 + et * dx, yy = y0 + et * dy;
+            ends[k][0] = xflag ? xx : xx >> shift, ends[k][1] = xflag ? yy >> shift : yy, ends[k][2] = et;
+        }
+        const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
+        const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            const int tend = ends[k][2];
+            for (int t0 = 0; t0 <= tend; t0 += 64) {
+                const int t = t0 + lane;
+                const int x = x0 + t * dx, y = y0 + t * dy;
+                int i1, j1;
+                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                const bool on = t <= tend && live(j1, i1);
+                unsigned long long bits = __ballot(on);
+                if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
+                if (good && th_on) {
+                    while (bits) {
+                        const int q = __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        const int tt = t0 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
+                        int ii, jj;
+                        if (xflag) jj = xx, ii = yy >> shift; else jj = xx >> shift, ii = yy;
+                        unvote(__float2int_rn((float)jj * ct + (float)ii * sn));
+                    }
+                }
+                lds_order();
+            }
+        }
+        if (good) {
+            if (g == 0 && lane == 0) {
+                int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
+                o[0] = e0x, o[1] = e0y, o[2] = e1x, o[3] = e1y;
+            }
+            if (++nlines >= cfg.max_segments) break;
+        }
+    }
+    if (g == 0 && lane == 0) nseg[s] = nlines;
+}
+
 // ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
 __device__ void jacobi3(double A[3][3], double V[3][3]) {        // symmetric eigen-decomposition, A -> diag
     for (int r = 0; r < 3; ++r)
@@ -1478,8 +1831,20 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* fb = rowcnt;       // the per-row counters are dead after compaction: reuse [s*h] as the fallback flag
     const bool use_fast = !(stages & 8);
     if (use_fast) {
+        // theta-sharded LDS variant first (4 workgroups per frame); frames it cannot hold, or where a partner did not
+        // show up in time, are flagged for houghp_fast, and what that cannot hold for houghp_kernel.
+        // AVHOT_HOUGH_SHARD=0 skips the first stage.
+        const char* e = getenv("AVHOT_HOUGH_SHARD");
+        const bool use_shard = !(e && atoi(e) == 0);
+        if (use_shard) {
+            hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 32 + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
+            AV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3(64), 0, st, h, w, L.numrho, hc, nz, npts, accum,
+                               lc->d_trig, segs, nseg, fb);
+            AV_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
-                           segs, nseg, fb);
+                           segs, nseg, fb, use_shard ? 1 : 0);
         AV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
