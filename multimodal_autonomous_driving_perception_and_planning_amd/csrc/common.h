@@ -126,6 +126,20 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = dpp_max_u32<0x143, 0xC>(v);
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Bitwise OR over the wave (0 is the identity, so the DPP operand folds like the max above).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_or_u32(unsigned v) {
+    return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v = dpp_or_u32<0xB1>(v);
+    v = dpp_or_u32<0x4E>(v);
+    v = dpp_or_u32<0x141>(v);
+    v = dpp_or_u32<0x140>(v);
+    v = dpp_or_u32<0x142, 0xA>(v);
+    v = dpp_or_u32<0x143, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // Lanes holding the maximum of v over the `valid` lanes, v >= +0.0 there (never NaN): non-negative
 // doubles order like their (hi, lo) words as unsigned integers, so two u32 reductions replace the
 // f64 compare/select chain.  Returns 0 when no lane is valid.

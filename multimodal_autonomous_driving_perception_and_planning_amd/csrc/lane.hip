@@ -1271,6 +1271,20 @@ __global__ void hough_prep_kernel(int n_streams, int numrho, int* __restrict__ a
     if (k == 0) fallback[s] = 0;
 }
 
+// cv::RNG(-1) is created afresh by every HoughLinesP call, so the draws of a frame are always the same sequence:
+// a table built at compile time replaces the multiply-with-carry chain (a 64-bit multiply per draw, serial).
+struct HoughDraws { unsigned v[HS_NZ]; };
+constexpr HoughDraws hough_draws() {
+    HoughDraws t{};
+    unsigned long long st = ~0ull;
+    for (int k = 0; k < HS_NZ; ++k) {
+        st = (unsigned long long)(unsigned)st * 4164903690ull + (unsigned)(st >> 32);
+        t.v[k] = (unsigned)st;
+    }
+    return t;
+}
+__device__ const HoughDraws g_draws = hough_draws();
+
 __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
@@ -1280,14 +1294,13 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
     __shared__ unsigned bm[HS_BMW];
     __shared__ int fifo[FIFO];
     __shared__ int bpt[HB];
-    __shared__ int didx[HB];
+    __shared__ float bfx[HB], bfy[HB];
     __shared__ int row_sz[64];
     __shared__ int sh_nb, sh_head, sh_tail, sh_count;
     const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x;
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(accum_all + (size_t)s * NUMANGLE * numrho);
     const int total = npts[s];
-    const int ymin = total > 0 ? (int)(nzg[0] >> 16) : 0, ymax = total > 0 ? (int)(nzg[total - 1] >> 16) : 0;
     const int wpr = (w + 31) >> 5;
     auto give_up = [&]() {
         if (lane == 0) fallback[s] = 1;
@@ -1297,20 +1310,39 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
-    if (total > HS_NZ || (ymax - ymin + 1) * wpr > HS_BMW || cfg.line_gap < 1) {        // same verdict in all HG workgroups
+    // the LDS clears do not depend on the point list: they run while its loads are in flight
+    for (int i = lane; i < HS_ACCW; i += 64) acc[i] = HS_BIAS | (HS_BIAS << 16);
+    for (int i = lane; i < HS_BMW; i += 64) bm[i] = 0;
+    if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups
+        give_up();
+        return;
+    }
+    constexpr int NZ_PER = HS_NZ / 64;
+    unsigned mine[NZ_PER];
+#pragma unroll
+    for (int k = 0; k < NZ_PER; ++k) mine[k] = k * 64 + lane < total ? nzg[k * 64 + lane] : 0u;
+    const int ymin = total > 0 ? (int)((unsigned)__builtin_amdgcn_readfirstlane((int)mine[0]) >> 16) : 0;
+    int ymax = 0;                                                                         // the list is sorted by (y, x)
+#pragma unroll
+    for (int k = 0; k < NZ_PER; ++k) ymax = k * 64 + lane < total && (int)(mine[k] >> 16) > ymax ? (int)(mine[k] >> 16) : ymax;
+    ymax = (int)wave_max_u32((unsigned)ymax);
+    if ((ymax - ymin + 1) * wpr > HS_BMW || cfg.line_gap < 1) {
         give_up();
         return;
     }
     if (lane == 0) sh_head = 0, sh_tail = 0, sh_count = total;
-    for (int i = lane; i < (ymax - ymin + 1) * wpr; i += 64) bm[i] = 0;
     lds_order();
     int xmn = w, xmx = 0;
-    for (int i = lane; i < total; i += 64) {
-        const unsigned p = nzg[i];
-        nz[i] = p;
-        const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
-        atomicOr(&bm[(y - ymin) * wpr + (x >> 5)], 1u << (x & 31));
-        xmn = x < xmn ? x : xmn, xmx = x > xmx ? x : xmx;
+#pragma unroll
+    for (int k = 0; k < NZ_PER; ++k) {
+        const int i = k * 64 + lane;
+        if (i < total) {
+            const unsigned p = mine[k];
+            nz[i] = p;
+            const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+            atomicOr(&bm[(y - ymin) * wpr + (x >> 5)], 1u << (x & 31));
+            xmn = x < xmn ? x : xmn, xmx = x > xmx ? x : xmx;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const int a = __shfl_xor(xmn, off, 64), b = __shfl_xor(xmx, off, 64);
@@ -1357,26 +1389,17 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
             return;
         }
         if (!th_on) my_lo = 0, my_base = 0;            // idle lanes read cell 0 (they add 0)
-        for (int i = lane; i < (my_tot + 1) / 2; i += 64) acc[i] = HS_BIAS | (HS_BIAS << 16);
-        lds_order();
+        (void)my_tot;
     }
-    auto cell = [&](int r, int& sh) -> unsigned* {
-        const int B = my_base + (r - my_lo);
-        sh = (B & 1) * 16;
-        return &acc[B >> 1];
-    };
-    auto vote = [&](int r, unsigned add) -> int {          // count BEFORE the vote (add = 0: a plain read)
-        int sh;
-        unsigned* p = cell(r, sh);
-        const unsigned old = atomicAdd(p, add << sh);
+    // cell index of (this lane's theta, rho of the pixel); idle lanes have ct = sn = 0 and land on cell 0
+    const int my_off = my_base - my_lo;
+    auto cellf = [&](float fx, float fy) { return __float2int_rn(fx * ct + fy * sn) + my_off; };
+    auto vote = [&](int B, unsigned add) -> int {          // count BEFORE the vote (add = 0: a plain read)
+        const int sh = (B & 1) * 16;
+        const unsigned old = atomicAdd(&acc[B >> 1], add << sh);
         return (int)((old >> sh) & 0xFFFFu) - (int)HS_BIAS;
     };
-    auto unvote = [&](int r) {
-        int sh;
-        unsigned* p = cell(r, sh);
-        atomicSub(p, 1u << sh);
-    };
-    auto rho = [&](int x, int y) { return th_on ? __float2int_rn((float)x * ct + (float)y * sn) : my_lo; };
+    auto unvote = [&](int B) { atomicSub(&acc[B >> 1], 1u << ((B & 1) * 16)); };
     // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope
     unsigned seq = 0;
     auto exchange = [&](int round, unsigned payload, unsigned (&got)[HG]) -> bool {
@@ -1401,31 +1424,43 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         for (int k = 0; k < HG; ++k) got[k] = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wv, k);
         return true;
     };
-    unsigned long long rng = ~0ull;
     int nlines = 0;
     const int shift = 16;
+    const int kk = lane & (HB - 1);                 // both half-waves work on draw kk of a top-up
+    unsigned r_next = kk < total ? g_draws.v[kk] : 0u;
     auto top_up = [&]() {
         const int cnt = sh_count, fill = sh_tail - sh_head;
         int nd = FIFO - HB - fill;
         nd = nd < HB ? nd : HB;
         nd = nd < cnt ? nd : cnt;
         if (nd <= 0) return;
-        unsigned r_mine = 0;
-        for (int k = 0; k < nd; ++k) {
-            rng = (unsigned long long)(unsigned)rng * 4164903690ull + (unsigned)(rng >> 32);
-            if (k == lane) r_mine = (unsigned)rng;
+        const unsigned r_mine = r_next;
+        {                                              // the next top-up's draws, in flight until then
+            const int nxt = total - cnt + nd + kk;
+            r_next = nxt < total ? g_draws.v[nxt] : 0u;
         }
-        if (lane < nd) didx[lane] = (int)(r_mine % (unsigned)(cnt - lane));
+        // cv's draw: step k takes nz[idx_k] and moves nz[cnt-1-k] into its place -- a chain when replayed literally.
+        // Resolved in registers instead: what position p holds at step k is what the ORIGINAL array holds at the
+        // position found by chasing p backwards through the earlier steps that wrote it.  The low half-wave does
+        // that for the picks, the high half for the elements moved in; only the last writer of a position stores.
+        const int idx = kk < nd ? (int)(r_mine % (unsigned)(cnt - kk)) : -1;
+        int p = lane < HB ? idx : cnt - 1 - kk;
+        bool last_writer = true;
+#pragma unroll
+        for (int k2 = HB - 1; k2 >= 0; --k2) {
+            const int ik = __builtin_amdgcn_readlane(idx, k2);       // -1 beyond nd: matches nothing
+            if (k2 < kk && ik == p) p = cnt - 1 - k2;
+            if (k2 > kk && ik == idx) last_writer = false;
+        }
+        unsigned v = 0;
+        if (kk < nd) v = nz[p];
         lds_order();
-        if (lane == 0) {
-            const int tail = sh_tail;
-            for (int k = 0; k < nd; ++k) {
-                const int idx = didx[k];
-                fifo[(tail + k) & (FIFO - 1)] = (int)nz[idx];
-                nz[idx] = nz[cnt - 1 - k];
-            }
-            sh_tail = tail + nd, sh_count = cnt - nd;
+        if (kk < nd) {
+            if (lane < HB) fifo[(sh_tail + kk) & (FIFO - 1)] = (int)v;
+            else if (last_writer) nz[idx] = v;
         }
+        lds_order();
+        if (lane == 0) sh_tail = sh_tail + nd, sh_count = cnt - nd;
         lds_order();
     };
     top_up();
@@ -1451,7 +1486,10 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
                     ok = live(p & 0xffff, p >> 16);
                 }
                 const unsigned long long okb = __ballot(ok);
-                if (ok) bpt[nb + __popcll(okb & ((1ull << lane) - 1ull))] = p;
+                if (ok) {
+                    const int slot = nb + __popcll(okb & ((1ull << lane) - 1ull));
+                    bpt[slot] = p, bfx[slot] = (float)(p & 0xffff), bfy[slot] = (float)(p >> 16);
+                }
                 nb += __popcll(okb);
                 head += take;
                 if (nb == HB) break;
@@ -1462,18 +1500,17 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         const int nb = sh_nb;
         if (nb == 0) break;
         // ---- speculative votes (LDS returning atomics, in order per lane) ---------------------------------------
-        int val[HB], pts[HB];
+        int val[HB], cel[HB];
 #pragma unroll
-        for (int b = 0; b < HB; ++b) pts[b] = bpt[b < nb ? b : 0];
+        for (int b = 0; b < HB; ++b) cel[b] = cellf(bfx[b < nb ? b : 0], bfy[b < nb ? b : 0]);
 #pragma unroll
-        for (int b = 0; b < HB; ++b) val[b] = vote(rho(pts[b] & 0xffff, pts[b] >> 16), (b < nb && th_on) ? 1u : 0u);
+        for (int b = 0; b < HB; ++b) val[b] = vote(cel[b], (b < nb && th_on) ? 1u : 0u);
         top_up();
-        unsigned hitbits = 0;
+        unsigned hm = 0;                                 // per lane: the points whose count reached the threshold here
 #pragma unroll
-        for (int b = 0; b < HB; ++b) {
-            val[b] = (b < nb && th_on) ? val[b] + 1 : 0;
-            if (__ballot(val[b] >= cfg.threshold && b < nb && th_on) != 0ull) hitbits |= 1u << b;
-        }
+        for (int b = 0; b < HB; ++b) hm |= val[b] + 1 >= cfg.threshold ? 1u << b : 0u;
+        hm = th_on ? hm & (nb == HB ? ~0u : (1u << nb) - 1u) : 0u;
+        const unsigned hitbits = wave_or_u32(hm);
         seq += 1;
         unsigned got[HG];
         if (!exchange(0, hitbits, got)) {
@@ -1488,14 +1525,14 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         int kv = 0;
 #pragma unroll
         for (int b = 0; b < HB; ++b)
-            if (b == bs) kv = val[b];
+            if (b == bs) kv = val[b] + 1;
         // counts can be negative (pixels erased before they voted): order-preserving signed -> unsigned map, 0 = no theta here
         const unsigned mykey = th_on ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
         const unsigned lbest = wave_max_u32(mykey);
         // the votes of the points after bs are withdrawn; they are re-examined after the line is erased
 #pragma unroll
         for (int b = 0; b < HB; ++b)
-            if (b > bs && b < nb && th_on) unvote(rho(bpt[b] & 0xffff, bpt[b] >> 16));
+            if (b > bs && b < nb && th_on) unvote(cel[b]);
         if (!exchange(1, lbest, got)) {
             give_up();
             return;
@@ -1541,6 +1578,20 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
                 const unsigned long long fo = __ballot(on), fi = __ballot(inb);
                 const int nin = fi == ~0ull ? 64 : __ffsll((long long)~fi) - 1;         // in-bounds steps of this word
                 int pos = 0;
+                if (cfg.line_gap >= 63 && nin > 0) {           // no run of zeros inside one word can exceed the gap
+                    const unsigned long long f = nin == 64 ? fo : fo & ((1ull << nin) - 1ull);
+                    if (f == 0ull) {
+                        if (gap + nin > cfg.line_gap) done = true;
+                        gap += nin;
+                    } else if (gap + (__ffsll((long long)f) - 1) > cfg.line_gap) {
+                        done = true;
+                    } else {
+                        const int last = 63 - __clzll((long long)f);
+                        et = t0 + last;
+                        gap = nin - 1 - last;
+                    }
+                    pos = nin;
+                }
                 while (pos < nin) {                                                        // the gap rule (line_gap >= 1)
                     const unsigned long long rest = fo >> pos;
                     int z = rest == 0ull ? 64 : __ffsll((long long)rest) - 1;            // zeros before the next hit
@@ -1575,14 +1626,14 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
                 const bool on = t <= tend && live(j1, i1);
                 unsigned long long bits = __ballot(on);
                 if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
-                if (good && th_on) {
+                if (good) {
+                    const float fj = (float)j1, fi = (float)i1;
                     while (bits) {
                         const int q = __ffsll((long long)bits) - 1;
                         bits &= bits - 1;
-                        const int tt = t0 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
-                        int ii, jj;
-                        if (xflag) jj = xx, ii = yy >> shift; else jj = xx >> shift, ii = yy;
-                        unvote(__float2int_rn((float)jj * ct + (float)ii * sn));
+                        const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fj), q));
+                        const float bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fi), q));
+                        if (th_on) unvote(cellf(bj, bi));
                     }
                 }
                 lds_order();
