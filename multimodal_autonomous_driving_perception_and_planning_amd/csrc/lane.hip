@@ -207,8 +207,11 @@ __device__ __forceinline__ unsigned uf_find(unsigned* lab, unsigned v) {      //
     unsigned i = v & 0x7fffffffu;
     unsigned cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while ((cur & 0x7fffffffu) != i) {
-        i = cur & 0x7fffffffu;
-        cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned p = cur & 0x7fffffffu;
+        const unsigned nxt = __hip_atomic_load(&lab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // path halving: labels only ever decrease along a path, so pointing i at its grandparent keeps the forest valid
+        if (nxt != cur) atomicMin(&lab[i], nxt);
+        i = p, cur = nxt;
     }
     return cur;
 }
@@ -631,101 +634,181 @@ __device__ __forceinline__ bool all_ones16(const uint4& v) {
     return v.x == 0x01010101u && v.y == 0x01010101u && v.z == 0x01010101u && v.w == 0x01010101u;
 }
 
-// Wave-balanced union pass: a wave scans 64 16-pixel chunks (one 16-byte load per lane), appends the
-// candidate pixels it finds to a wave-private LDS list, then the lanes share the list evenly -- edges
-// cluster, so without this one lane would walk all 16 candidates of a chunk (4 unions each) alone.
-__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map, int h, int w, int n_frames,
-                                                      unsigned* __restrict__ labels) {
-    __shared__ unsigned list[4][1024];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int cw = w >> 4;
-    const long long total = (long long)n_frames * h * cw;
-    const long long c0 = ((long long)blockIdx.x * 4 + wid) * 64;
-    if (c0 >= total) return;
-    const long long ci = c0 + lane;
-    unsigned cand = 0;                                   // bit k: pixel k of this lane's chunk is a candidate
-    int s = 0, y = 0, xb = 0;
-    if (ci < total) {
-        s = (int)(ci / ((long long)h * cw));
-        const int r = (int)(ci - (long long)s * h * cw);
-        y = r / cw, xb = (r - y * cw) * 16;
-        const uint4 v = *reinterpret_cast<const uint4*>(map + ((size_t)s * h + y) * w + xb);
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+// Chunk index inside a frame -> (row, first column) without an integer division: float reciprocal, then the
+// remainder puts an off-by-one quotient right (exact for ci < 2^24 chunks = 268 M pixels per frame).
+__device__ __forceinline__ void chunk_xy(unsigned ci, int cw, float rcw, int& y, int& xb) {
+    unsigned q = (unsigned)((float)ci * rcw);
+    int r = (int)(ci - q * (unsigned)cw);
+    if (r < 0) --q, r += cw;
+    else if (r >= cw) ++q, r -= cw;
+    y = (int)q, xb = r * 16;
+}
+
+// Horizontal runs inside a 16-pixel chunk are one component: point every pixel of a run at the run's smallest label
+// (its first strong pixel, else its first pixel) before any union is made -- plain stores in a pass of their own,
+// instead of 15 unions per run (each a chain of dependent atomics) in the union pass.
+__global__ void __launch_bounds__(256) ccl_runs_fast(const uint8_t* __restrict__ map_all, int h, int w,
+                                                     unsigned* __restrict__ labels_all) {
+    const int s = blockIdx.y;
+    const unsigned total = (unsigned)(h * (w >> 4));
+    const unsigned ci = blockIdx.x * 256u + threadIdx.x;
+    if (ci >= total) return;
+    const uint4 v = *reinterpret_cast<const uint4*>(map_all + (size_t)s * h * w + (size_t)ci * 16);
+    if (all_ones16(v)) return;
+    unsigned* lab = labels_all + (size_t)s * h * w;
+    unsigned cand = 0, strong = 0;
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k;
-    }
-    const int mine = __popc(cand);
-    if (__ballot(mine != 0) == 0ull) return;
-    // exclusive prefix of `mine` over the wave
-    int off = mine;
+    for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
+    const unsigned cbase = ci * 16u;
+    unsigned rest = cand;
+    while (rest) {
+        const int a = __ffs((int)rest) - 1;
+        const unsigned run = rest & ~(rest + (1u << a));           // the contiguous ones starting at bit a
+        rest &= ~run;
+        if ((run & (run - 1)) == 0) continue;                       // a single pixel
+        const unsigned sr = strong & run;
+        const int rp = sr ? __ffs((int)sr) - 1 : a;
+        const unsigned rep = sr ? cbase + (unsigned)rp : (cbase + (unsigned)rp) | 0x80000000u;
+        const unsigned todo = run & ~(1u << rp);
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(off, d, 64);
-        if (lane >= d) off += o;
-    }
-    const int n = __shfl(off, 63, 64);
-    off -= mine;
-    unsigned bits = cand;
-    while (bits) {
-        const int k = __ffs((int)bits) - 1;
-        bits &= bits - 1;
-        list[wid][off++] = (unsigned)lane << 4 | (unsigned)k;     // (lane of the chunk, pixel in chunk)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    for (int i = lane; i < n; i += 64) {
-        const unsigned e = list[wid][i];
-        const long long cj = c0 + (e >> 4);
-        const int sj = (int)(cj / ((long long)h * cw));
-        const int rj = (int)(cj - (long long)sj * h * cw);
-        const int yj = rj / cw, x = (rj - yj * cw) * 16 + (int)(e & 15u);
-        const uint8_t* m = map + (size_t)sj * h * w;
-        unsigned* lab = labels + (size_t)sj * h * w;
-        const unsigned me = (unsigned)(yj * w + x);
-        if (x > 0 && m[(size_t)yj * w + x - 1] != 1) uf_union(lab, me, me - 1);
-        if (yj > 0) {
-            const size_t up = (size_t)(yj - 1) * w;
-            if (x > 0 && m[up + x - 1] != 1) uf_union(lab, me, (unsigned)(up + x - 1));
-            if (m[up + x] != 1) uf_union(lab, me, (unsigned)(up + x));
-            if (x + 1 < w && m[up + x + 1] != 1) uf_union(lab, me, (unsigned)(up + x + 1));
-        }
+        for (int k = 0; k < 16; ++k)
+            if ((todo >> k) & 1u) lab[cbase + (unsigned)k] = rep;
     }
 }
 
-__global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map, int h, int w, int n_frames,
-                                                     unsigned* __restrict__ labels, Roi roi,
-                                                     const int* __restrict__ roi_rows, uint8_t* __restrict__ edges,
-                                                     uint8_t* __restrict__ masked, int* __restrict__ rowcnt) {
+// Wave-balanced union pass: a wave scans 64 16-pixel chunks (one 16-byte load per lane), appends the candidate
+// pixels to a wave-private LDS list, then the lanes share the list evenly -- edges cluster, so without this one
+// lane would walk all 16 candidates of a chunk alone.  Grid: (chunk groups of one frame, frame).
+constexpr int CCK = 1;        // groups per wave; 4 was slower (145 vs 122 us): it only lengthens each wave's chain of dependent atomics
+__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map_all, int h, int w,
+                                                      unsigned* __restrict__ labels_all) {
+    __shared__ unsigned list[4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = blockIdx.y;
     const int cw = w >> 4;
-    const long long total = (long long)n_frames * h * cw;
-    const long long ci = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (ci >= total) return;
-    const int s = (int)(ci / ((long long)h * cw));
-    const int r = (int)(ci - (long long)s * h * cw);
-    const int y = r / cw, xb = (r - y * cw) * 16;
-    const size_t off = ((size_t)s * h + y) * w + xb;
-    const uint4 cur4 = *reinterpret_cast<const uint4*>(map + off);
-    uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
-    if (!all_ones16(cur4)) {
-        unsigned* lab = labels + (size_t)s * h * w;
-        int xl, xr, cnt = 0;
-        roi_bounds(roi, h, y, roi_rows, xl, xr);
-        const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4);
-        uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
-        uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
-        for (int q = 0; q < 16; ++q) {
-            if (cur[q] == 1) continue;
-            const int xx = xb + q;
-            if (!(uf_find(lab, (unsigned)(y * w + xx)) >> 31)) {
-                e[q] = 255;
-                if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
+    const float rcw = 1.0f / (float)cw;
+    const unsigned total = (unsigned)(h * cw);
+    const unsigned c0 = (blockIdx.x * 4u + (unsigned)wid) * (64u * CCK);
+    if (c0 >= total) return;
+    const uint8_t* m = map_all + (size_t)s * h * w;
+    unsigned* lab = labels_all + (size_t)s * h * w;
+    uint4 v[CCK];
+#pragma unroll
+    for (int g = 0; g < CCK; ++g) {
+        const unsigned ci = c0 + (unsigned)(g * 64 + lane);
+        v[g] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (ci < total) v[g] = *reinterpret_cast<const uint4*>(m + (size_t)ci * 16);      // w % 16 == 0: chunk ci starts at byte 16 ci
+    }
+#pragma unroll
+    for (int g = 0; g < CCK; ++g) {
+        unsigned cand = 0;                               // bit k: pixel k of this lane's chunk is a candidate
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v[g]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k;
+        const int mine = __popc(cand);
+        if (__ballot(mine != 0) == 0ull) continue;
+        int off = mine;                                  // exclusive prefix of `mine` over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(off, d, 64);
+            if (lane >= d) off += o;
+        }
+        const int n = __shfl(off, 63, 64);
+        off -= mine;
+        unsigned bits = cand;
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            // (pixel in chunk, lane of the chunk, left / right neighbour inside the chunk is a candidate)
+            list[wid][off++] = (unsigned)k | (unsigned)lane << 4 |
+                               (k > 0 ? ((cand >> (k - 1)) & 1u) << 10 : 0u) | (k < 15 ? ((cand >> (k + 1)) & 1u) << 11 : 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        for (int i = lane; i < n; i += 64) {
+            const unsigned e = list[wid][i];
+            int yj, xb;
+            chunk_xy(c0 + (unsigned)(g * 64) + ((e >> 4) & 63u), cw, rcw, yj, xb);
+            const int x = xb + (int)(e & 15u);
+            const unsigned me = (unsigned)(yj * w + x);
+            // Links to the row above, once per pair of runs: pixels of one run are one component already (and so are
+            // the runs up there, by whoever owns that row), so a link that the left or right neighbour of this pixel
+            // makes as well is skipped.  L / R: the neighbour in this row is a candidate.
+            const unsigned k = e & 15u;
+            const uint8_t* row = m + (size_t)yj * w;
+            const bool L = k > 0 ? (e >> 10) & 1u : (x > 0 && row[x - 1] != 1);
+            const bool R = k < 15 ? (e >> 11) & 1u : (x + 1 < w && row[x + 1] != 1);
+            if (k == 0 && L) uf_union(lab, me, me - 1);                       // inside a chunk the run is linked already
+            if (yj > 0) {
+                const uint8_t* upr = row - w;
+                const bool UL = x > 0 && upr[x - 1] != 1, UC = upr[x] != 1, UR = x + 1 < w && upr[x + 1] != 1;
+                const unsigned up = (unsigned)((yj - 1) * w + x);
+                if (UC) {
+                    if (!(L && UL)) uf_union(lab, me, up);
+                } else {
+                    if (UL && !L) uf_union(lab, me, up - 1);
+                    if (UR && !R) uf_union(lab, me, up + 1);
+                }
             }
         }
-        if (cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");      // the list is reused by the next group
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
-    if (edges) *reinterpret_cast<uint4*>(edges + off) = e4;
-    *reinterpret_cast<uint4*>(masked + off) = k4;
+}
+
+// Resolve every candidate's component (strong root = an edge), apply the ROI, count the ROI edges per row.
+// A thread takes FCK 16-pixel chunks a workgroup-stride apart (coalesced per trip, loads in flight together).
+constexpr int FCK = 4;
+__global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map_all, int h, int w,
+                                                     unsigned* __restrict__ labels_all, Roi roi,
+                                                     const int* __restrict__ roi_rows, uint8_t* __restrict__ edges_all,
+                                                     uint8_t* __restrict__ masked_all, int* __restrict__ rowcnt) {
+    const int cw = w >> 4, s = blockIdx.y;
+    const float rcw = 1.0f / (float)cw;
+    const unsigned total = (unsigned)(h * cw);
+    const unsigned c0 = blockIdx.x * (256u * FCK) + threadIdx.x;
+    const size_t fo = (size_t)s * h * w;
+    const uint8_t* m = map_all + fo;
+    unsigned* lab = labels_all + fo;
+    uint4 cur4[FCK];
+#pragma unroll
+    for (int g = 0; g < FCK; ++g) {
+        const unsigned ci = c0 + (unsigned)g * 256u;
+        cur4[g] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (ci < total) cur4[g] = *reinterpret_cast<const uint4*>(m + (size_t)ci * 16);
+    }
+#pragma unroll
+    for (int g = 0; g < FCK; ++g) {
+        const unsigned ci = c0 + (unsigned)g * 256u;
+        if (ci >= total) break;
+        uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
+        if (!all_ones16(cur4[g])) {
+            int y, xb, xl, xr, cnt = 0;
+            chunk_xy(ci, cw, rcw, y, xb);
+            roi_bounds(roi, h, y, roi_rows, xl, xr);
+            const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4[g]);
+            uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
+            uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
+            bool run_on = false, keep = false;               // adjacent candidates share their component: one find per run
+            for (int q = 0; q < 16; ++q) {
+                if (cur[q] == 1) {
+                    run_on = false;
+                    continue;
+                }
+                const int xx = xb + q;
+                if (!run_on) keep = !(uf_find(lab, (unsigned)(y * w + xx)) >> 31), run_on = true;
+                if (keep) {
+                    e[q] = 255;
+                    if (xx >= xl && xx <= xr) k[q] = 255, ++cnt;
+                }
+            }
+            if (cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
+        }
+        if (edges_all) *reinterpret_cast<uint4*>(edges_all + fo + (size_t)ci * 16) = e4;
+        *reinterpret_cast<uint4*>(masked_all + fo + (size_t)ci * 16) = k4;
+    }
 }
 
 // ---- L4a: row-major list of edge points -----------------------------------------------------------------------
@@ -1847,7 +1930,8 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* segs = (int*)(ws + L.segs);
     int* nseg = (int*)(ws + L.nseg);
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
-    const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0;
+    const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0 &&
+                       (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
     const bool streamp = (w % 4 == 0) && w >= 8 && (((size_t)bgr | (size_t)workspace) & 15) == 0 && !(stages & 4);
     const dim3 sgrid((w + SW - 1) / SW, (h + 4 * SROWS - 1) / (4 * SROWS), n_streams);
     if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
@@ -1860,17 +1944,19 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
     else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
     AV_LAUNCH_CHECK();
-    const long long nchunks = (long long)n_streams * h * (w >> 4);
-    const dim3 chunks((unsigned)((nchunks + 255) / 256));
-    if (fastp) hipLaunchKernelGGL(ccl_merge_fast, chunks, dim3(256), 0, st, map, h, w, n_streams, labels);
-    else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
+    const unsigned fchunks = (unsigned)h * (unsigned)(w >> 4);                 // 16-pixel chunks of one frame
+    if (fastp) {
+        hipLaunchKernelGGL(ccl_runs_fast, dim3((fchunks + 255) / 256, n_streams), dim3(256), 0, st, map, h, w, labels);
+        hipLaunchKernelGGL(ccl_merge_fast, dim3((fchunks + 256 * CCK - 1) / (256 * CCK), n_streams), dim3(256), 0, st, map, h, w,
+                           labels);
+    } else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
     AV_LAUNCH_CHECK();
     Roi roi;
     roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
     roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
     if (fastp)
-        hipLaunchKernelGGL(finalize_fast, chunks, dim3(256), 0, st, map, h, w, n_streams, labels, roi, roi_rows,
-                           (stages & 1) ? edges : nullptr, masked, rowcnt);
+        hipLaunchKernelGGL(finalize_fast, dim3((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams), dim3(256), 0, st, map, h, w,
+                           labels, roi, roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
     else
         hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
                            roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
