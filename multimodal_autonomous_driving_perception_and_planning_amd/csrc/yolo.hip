@@ -392,16 +392,49 @@ __global__ void __launch_bounds__(1024) nms_sort_kernel(int A, float conf_thres,
         key[i] = k;
     }
     __syncthreads();
-    for (int sz = 2; sz <= MAX_CAND; sz <<= 1)
-        for (int st = sz >> 1; st > 0; st >>= 1) {
+    // bitonic network; strides >= 8 go through LDS one stage per barrier, the last three stages of every merge
+    // (strides 4, 2, 1) stay inside a thread's 8 consecutive keys and run in registers
+    static_assert(MAX_CAND % 8192 == 0, "a thread owns 8 consecutive keys per 8192");
+    auto cmpx = [](unsigned long long& a, unsigned long long& b, bool up) {
+        if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
+    };
+    for (int sz = 2; sz <= MAX_CAND; sz <<= 1) {
+        for (int ls = 31 - __clz(sz >> 1); ls >= 3; --ls) {
+            const int st = 1 << ls;
             for (int i = tid; i < MAX_CAND / 2; i += 1024) {
-                const int lo = (i / st) * 2 * st + (i % st), hi = lo + st;
+                const int lo = ((i >> ls) << (ls + 1)) | (i & (st - 1)), hi = lo + st;
                 const bool up = ((lo & sz) == 0);
                 const unsigned long long a = key[lo], b = key[hi];
                 if ((a > b) == up) key[lo] = b, key[hi] = a;
             }
             __syncthreads();
         }
+        for (int base = tid * 8; base < MAX_CAND; base += 8192) {
+            unsigned long long k[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) k[q] = key[base + q];
+            const bool up = ((base & sz) == 0);                  // sz >= 8: one direction for the whole octet
+            if (sz >= 8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cmpx(k[q], k[q + 4], up);
+            }
+            if (sz >= 4) {
+#pragma unroll
+                for (int q = 0; q < 8; q += 4) {
+                    const bool u = sz >= 8 ? up : (((base + q) & sz) == 0);
+                    cmpx(k[q], k[q + 2], u), cmpx(k[q + 1], k[q + 3], u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                const bool u = sz >= 8 ? up : (((base + q) & sz) == 0);
+                cmpx(k[q], k[q + 1], u);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) key[base + q] = k[q];
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < A; i += 1024) {
         const unsigned long long k = key[i];
         if (k != ~0ull) {
@@ -782,6 +815,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     hipStream_t st = as_stream(stream);
     const hipStream_t st_main = st;
     const int B = y.B;
+    const bool force_direct = getenv("AVHOT_CONV_DIRECT") != nullptr;      // tuning aid, read once per forward
     {
         const int n = B * y.H * y.W;
         hipLaunchKernelGGL(preprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
@@ -800,7 +834,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
             // a partial 32-channel chunk is zero-filled) and for 1x1 with whole chunks; stride 2 and the rest stay direct
             const bool lds_ok = a.stride == 1 && ((a.ksz == 3 && a.cin >= 16 && a.cin % 8 == 0) || (a.ksz == 1 && a.cin % LT_CK == 0));
-            if (lds_ok && !getenv("AVHOT_CONV_DIRECT")) {
+            if (lds_ok && !force_direct) {
                 const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
                 const int taps = a.ksz * a.ksz;
                 const int PH = (LT_H - 1) * a.stride + a.ksz, PW = (LT_W - 1) * a.stride + a.ksz;
