@@ -84,3 +84,27 @@ def test_object_detector_yolo_mode(setup):
     # a missing checkpoint degrades to simulated mode like the reference without ultralytics (detector.py:79-84)
     fb = ObjectDetector(mode="yolo", model_path="yolov8n.pt")
     assert fb.mode == "simulated" and 3 <= len(fb.detect(frame)) <= 7
+
+
+def test_batch_of_different_frames_matches_single_image_runs(setup):
+    """bench config3 runs 64 frames per launch: every image of a batch must come out exactly as it does alone
+    (same kernels, per-image tiles; nothing may leak across the image index)."""
+    import torch
+    Y, R, frame, feats, model, got = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame, synthetic_frame(720, 1280, 3, 11), np.full((720, 1280, 3), 128, np.uint8), synthetic_frame(720, 1280, 6, 40),
+              synthetic_frame(720, 1280, 1, 5)]
+    B = len(frames)
+    batched = Y.YoloV8n("random:0", batch=B)
+    batched._prepare(720, 1280)
+    batched._frames.copy_(torch.as_tensor(np.stack(frames)))
+    batched.forward_device(batched._frames)
+    torch.cuda.synchronize()
+    n = batched._n.cpu().numpy()
+    box, conf, cls = batched._box.cpu().numpy(), batched._conf.cpu().numpy(), batched._cls.cpu().numpy()
+    for b in range(B):
+        sb, sc, sk = model.detect(frames[b])
+        assert n[b] == len(sc) > 0, b
+        assert np.array_equal(box[b, :n[b]], sb) and np.array_equal(conf[b, :n[b]], sc) and np.array_equal(cls[b, :n[b]], sk), b
+    assert not np.array_equal(box[0, :8], box[1, :8])            # the frames really differ
+    batched.close()
