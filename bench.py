@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step (no one-step-late Hough half)")
     ap.add_argument("--taggers", action="store_true",
                     help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
     return ap.parse_args()
@@ -79,13 +80,23 @@ def bench_config3(a, world, rank, local):
         dist.barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
+        # PerceptionLoop.step_deferred() with events around the detector: the lane chain runs beside it on the side
+        # stream (both only read the frames), its Hough + fit half one step late so that it meets the detector's
+        # LDS-free first kernels; the last frame's half is flushed inside the timed region
         loop.enqueue_generate(stream0=rank * S)
-        nat.check(L.av_fork(loop.ctx.handle, loop._s))           # lane chain beside the detector (both only read the frames)
-        loop.enqueue_lanes(loop.ctx.side_stream)
+        nat.check(L.av_fork(loop.ctx.handle, loop._s))
+        if not a.no_defer:
+            if loop._lanes_pending:
+                loop.enqueue_lanes(loop.ctx.side_stream, stages=16)
+            loop.enqueue_lanes(loop.ctx.side_stream, stages=2)
+            loop._lanes_pending = True
+        else:
+            loop.enqueue_lanes(loop.ctx.side_stream)
         nat.check(L.av_event_record(evs[k][0], loop._s))
         loop.enqueue_detect()
         nat.check(L.av_event_record(evs[k][1], loop._s))
         nat.check(L.av_join(loop.ctx.handle, loop._s))
+    loop.flush_lanes()
     loop.synchronize()
     torch.cuda.synchronize()
     if world > 1:

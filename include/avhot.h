@@ -230,7 +230,9 @@ int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segmen
  *   info       int32 [S][8]    valid_left valid_right n_left_segments n_right_segments n_segments n_points lo hi
  *   conf       double [S][2]   min(1, n_side_segments / 10)
  *   stages     bit0: also write the pre-ROI Canny edge map (view 2); bit1: stop after the pixel stages
- *              (no Hough, no fit) */
+ *              (no Hough, no fit); bit4: skip the pixel stages and run Hough + fit on what the last bit1 call left
+ *              in the workspace -- the two halves of a frame can then be enqueued apart, e.g. the Hough half beside
+ *              the next frame's LDS-free kernels (it holds most of a CU's LDS) */
 int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int n_streams, int h, int w,
                    const uint8_t* bgr, const int32_t* roi_rows, void* workspace, double* lane_state,
                    double* poly, int32_t* pts, int32_t* info, double* conf, int stages);

@@ -1933,36 +1933,38 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0 &&
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
     const bool streamp = (w % 4 == 0) && w >= 8 && (((size_t)bgr | (size_t)workspace) & 15) == 0 && !(stages & 4);
-    const dim3 sgrid((w + SW - 1) / SW, (h + 4 * SROWS - 1) / (4 * SROWS), n_streams);
-    if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
-    else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
-    else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
-    AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
-    AV_LAUNCH_CHECK();
-    if (streamp) hipLaunchKernelGGL(sobel_nms_stream, sgrid, dim3(256), 0, st, blur, h, w, thr, map, labels);
-    else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
-    else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
-    AV_LAUNCH_CHECK();
-    const unsigned fchunks = (unsigned)h * (unsigned)(w >> 4);                 // 16-pixel chunks of one frame
-    if (fastp) {
-        hipLaunchKernelGGL(ccl_runs_fast, dim3((fchunks + 255) / 256, n_streams), dim3(256), 0, st, map, h, w, labels);
-        hipLaunchKernelGGL(ccl_merge_fast, dim3((fchunks + 256 * CCK - 1) / (256 * CCK), n_streams), dim3(256), 0, st, map, h, w,
-                           labels);
-    } else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
-    AV_LAUNCH_CHECK();
-    Roi roi;
-    roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
-    roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
-    if (fastp)
-        hipLaunchKernelGGL(finalize_fast, dim3((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams), dim3(256), 0, st, map, h, w,
-                           labels, roi, roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
-    else
-        hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
-                           roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
-    AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
-    AV_LAUNCH_CHECK();
+    if (!(stages & 16)) {                                          // bit 4: Hough + fit only, on the point lists already in the workspace
+        const dim3 sgrid((w + SW - 1) / SW, (h + 4 * SROWS - 1) / (4 * SROWS), n_streams);
+        if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
+        else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+        else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+        AV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
+        AV_LAUNCH_CHECK();
+        if (streamp) hipLaunchKernelGGL(sobel_nms_stream, sgrid, dim3(256), 0, st, blur, h, w, thr, map, labels);
+        else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+        else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+        AV_LAUNCH_CHECK();
+        const unsigned fchunks = (unsigned)h * (unsigned)(w >> 4);                 // 16-pixel chunks of one frame
+        if (fastp) {
+            hipLaunchKernelGGL(ccl_runs_fast, dim3((fchunks + 255) / 256, n_streams), dim3(256), 0, st, map, h, w, labels);
+            hipLaunchKernelGGL(ccl_merge_fast, dim3((fchunks + 256 * CCK - 1) / (256 * CCK), n_streams), dim3(256), 0, st, map, h, w,
+                               labels);
+        } else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
+        AV_LAUNCH_CHECK();
+        Roi roi;
+        roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
+        roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
+        if (fastp)
+            hipLaunchKernelGGL(finalize_fast, dim3((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams), dim3(256), 0, st, map, h, w,
+                               labels, roi, roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
+        else
+            hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
+                               roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
+        AV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
+        AV_LAUNCH_CHECK();
+    }
     if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)
     HoughCfg hc{cfg->hough_threshold, cfg->min_line_length, cfg->max_line_gap, cfg->max_segments};
     int* fb = rowcnt;       // the per-row counters are dead after compaction: reuse [s*h] as the fallback flag

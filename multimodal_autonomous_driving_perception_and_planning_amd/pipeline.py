@@ -257,6 +257,7 @@ class PerceptionLoop:
             sizes.append((cin, cout, k, s))
         self.flops_per_frame = _yolo_flops(net_h, net_w)
         self.frame_idx = 0
+        self._lanes_pending = False
         self.stream.synchronize()
 
     @property
@@ -273,10 +274,12 @@ class PerceptionLoop:
                                          nat.ptr(self.det_n), nat.ptr(self.det_box), nat.ptr(self.det_conf),
                                          nat.ptr(self.det_cls)))
 
-    def enqueue_lanes(self, stream=None):
+    def enqueue_lanes(self, stream=None, stages=0):
+        """stages 0: the whole chain; 2: pixel stages only (edge points left in the workspace); 16: Hough + fit of
+        what the last pixel-stage call left there."""
         nat.check(self.L.av_lane_detect(self.ctx.handle, stream or self._s, C.byref(self.lcfg), self.S, self.h, self.w,
                                         nat.ptr(self.frames), None, nat.ptr(self.ws), nat.ptr(self.lane_state),
-                                        nat.ptr(self.poly), nat.ptr(self.pts), nat.ptr(self.info), nat.ptr(self.conf), 0))
+                                        nat.ptr(self.poly), nat.ptr(self.pts), nat.ptr(self.info), nat.ptr(self.conf), stages))
 
     def step(self, sync=False):
         """generate; fork{lanes} || {detect}; join.  The detector and the lane chain only share the frames: the
@@ -289,6 +292,28 @@ class PerceptionLoop:
         nat.check(self.L.av_join(h, self._s))
         if sync:
             self.stream.synchronize()
+
+    def step_deferred(self):
+        """Throughput variant of step(): the Hough + fit half of a frame's lane chain is enqueued one step late, ahead
+        of the next frame's pixel stages on the side stream.  The sharded PPHT holds 158 KB of LDS on every CU it
+        runs on, which keeps the LDS-tiled convolutions off those CUs; one step late it runs beside the detector's
+        preprocess + stem + first stride-2 convolution, which use no LDS.  Same kernels, same per-stream order, same
+        results; the lane outputs (poly / pts / info / conf) describe the PREVIOUS frame until flush_lanes()."""
+        h = self.ctx.handle
+        self.enqueue_generate()
+        nat.check(self.L.av_fork(h, self._s))
+        if self._lanes_pending:
+            self.enqueue_lanes(self.ctx.side_stream, stages=16)
+        self.enqueue_lanes(self.ctx.side_stream, stages=2)
+        self._lanes_pending = True
+        self.enqueue_detect()
+        nat.check(self.L.av_join(h, self._s))
+
+    def flush_lanes(self):
+        """Hough + fit of the last frame step_deferred() left pending."""
+        if self._lanes_pending:
+            self.enqueue_lanes(stages=16)
+            self._lanes_pending = False
 
     def synchronize(self):
         self.stream.synchronize()

@@ -121,6 +121,7 @@ def test_perception_loop_step_matches_per_frame_paths(setup):
     S, h, w = 3, 720, 1280
     loop = PerceptionLoop(n_streams=S, h=h, w=w)
     refs = [LaneRef() for _ in range(S)]
+    seen = []
     for step in range(3):
         loop.step(sync=True)
         torch.cuda.synchronize()
@@ -138,3 +139,21 @@ def test_perception_loop_step_matches_per_frame_paths(setup):
                     assert np.abs(pts[s, side] - exp[0]).max() <= 1
             sb, sc, sk = model.detect(fr[s])
             assert n[s] == len(sc) and np.array_equal(box[s, :n[s]], sb), (step, s)
+        seen.append((info.copy(), poly.copy(), pts.copy(), loop.conf.cpu().numpy(), n.copy(), box.copy()))
+    # throughput variant: the Hough + fit half of the lane chain one step late -- same results, one step later
+    loop2 = PerceptionLoop(n_streams=S, h=h, w=w)
+
+    def lanes_equal(k):
+        got = (loop2.info.cpu().numpy(), loop2.poly.cpu().numpy(), loop2.pts.cpu().numpy(), loop2.conf.cpu().numpy())
+        return all(np.array_equal(a, b) for a, b in zip(got, seen[k][:4]))
+    for step in range(3):
+        loop2.step_deferred()
+        loop2.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(loop2.det_n.cpu().numpy(), seen[step][4]) and np.array_equal(loop2.det_box.cpu().numpy(), seen[step][5])
+        if step:
+            assert lanes_equal(step - 1), step
+    loop2.flush_lanes()
+    loop2.synchronize()
+    torch.cuda.synchronize()
+    assert lanes_equal(2)
