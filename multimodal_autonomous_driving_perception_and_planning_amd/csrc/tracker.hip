@@ -161,11 +161,36 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
         }
         if (det2trk && row < dcap) det2trk[sfo * dcap + row] = sh.d2t[row];
     };
+    // replica kernel: next chunk's detections, one element per thread, in flight during the current chunk
+    int4 pf_box = make_int4(0, 0, 0, 0);
+    int pf_cls = 0, pf_n = 0;
+    double pf_conf = 0.0;
+    auto prefetch = [&](size_t sf0, int nfr) {
+        if (tid < nfr) pf_n = det_n[sf0 + tid];
+        if (tid < nfr * dcap) {
+            pf_box = reinterpret_cast<const int4*>(det_box)[sf0 * dcap + tid];
+            pf_cls = det_cls[sf0 * dcap + tid];
+            pf_conf = det_conf[sf0 * dcap + tid];
+        }
+    };
+    if (REPL && n_frames > 0) prefetch((size_t)s * n_frames, n_frames < FC ? n_frames : FC);
     int fl = -1;                               // frame within the staged chunk
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
         fl = (fl + 1 == FC) ? 0 : fl + 1;
-        if (fl == 0) {
+        if (REPL && fl == 0) {
+            // the chunk was fetched into registers while the previous one was being processed (one element per
+            // thread: FC * dcap <= 512): hand it to LDS and start fetching the next one
+            lds_sync<true>();
+            if (tid < FC) c_n[tid] = pf_n;
+            if (tid < FC * dcap) {
+                reinterpret_cast<int4*>(c_box)[tid] = pf_box;
+                c_area[tid] = (double)(pf_box.z - pf_box.x) * (double)(pf_box.w - pf_box.y);
+                c_cls[tid] = pf_cls, c_conf[tid] = pf_conf;
+            }
+            lds_sync<true>();
+            if (f + FC < n_frames) prefetch(sf + FC, (n_frames - f - FC) < FC ? (n_frames - f - FC) : FC);
+        } else if (fl == 0) {
             // one cooperative load of the next FC frames' detections; the only global reads of the loop
             const int nfr = (n_frames - f) < FC ? (n_frames - f) : FC;
             lds_sync<MULTIWAVE || REPL>();
