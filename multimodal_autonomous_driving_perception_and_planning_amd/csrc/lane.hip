@@ -644,117 +644,157 @@ __device__ __forceinline__ void chunk_xy(unsigned ci, int cw, float rcw, int& y,
     y = (int)q, xb = r * 16;
 }
 
-// Horizontal runs inside a 16-pixel chunk are one component: point every pixel of a run at the run's smallest label
-// (its first strong pixel, else its first pixel) before any union is made -- plain stores in a pass of their own,
-// instead of 15 unions per run (each a chain of dependent atomics) in the union pass.
-__global__ void __launch_bounds__(256) ccl_runs_fast(const uint8_t* __restrict__ map_all, int h, int w,
-                                                     unsigned* __restrict__ labels_all) {
-    const int s = blockIdx.y;
-    const unsigned total = (unsigned)(h * (w >> 4));
-    const unsigned ci = blockIdx.x * 256u + threadIdx.x;
-    if (ci >= total) return;
-    const uint4 v = *reinterpret_cast<const uint4*>(map_all + (size_t)s * h * w + (size_t)ci * 16);
-    if (all_ones16(v)) return;
-    unsigned* lab = labels_all + (size_t)s * h * w;
-    unsigned cand = 0, strong = 0;
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
-    const unsigned cbase = ci * 16u;
-    unsigned rest = cand;
-    while (rest) {
-        const int a = __ffs((int)rest) - 1;
-        const unsigned run = rest & ~(rest + (1u << a));           // the contiguous ones starting at bit a
-        rest &= ~run;
-        if ((run & (run - 1)) == 0) continue;                       // a single pixel
-        const unsigned sr = strong & run;
-        const int rp = sr ? __ffs((int)sr) - 1 : a;
-        const unsigned rep = sr ? cbase + (unsigned)rp : (cbase + (unsigned)rp) | 0x80000000u;
-        const unsigned todo = run & ~(1u << rp);
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if ((todo >> k) & 1u) lab[cbase + (unsigned)k] = rep;
+// ---- hysteresis, tiled: components are first resolved inside 16 x 256 tiles with the labels in LDS (a union there
+// is a few LDS round trips; in global memory it is a chain of dependent atomics that large components serialise on),
+// every candidate is then pointed at its tile-local root in the global label array, and only the links that cross a
+// tile border are made with global unions.  Same label order (strong < weak), so the verdict "root is strong" and
+// with it the edge map are unchanged.  Tile height: 64 rows 90 us, 32 rows 52 us, 16 rows 36 us per 64 frames (LDS per
+// workgroup sets the occupancy, and most tiles hold no candidate at all); the border pass grows from 13 to 17 us.
+constexpr int CT_R = 16, CT_C = 256, CT_CH = CT_C / 16, CT_NCH = CT_R * CT_CH, CT_PX = CT_R * CT_C;
+
+__device__ __forceinline__ unsigned lds_find(unsigned* lab, unsigned v) {
+    unsigned i = v & 0x7fffffffu;
+    unsigned cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((cur & 0x7fffffffu) != i) {
+        i = cur & 0x7fffffffu;
+        cur = __hip_atomic_load(&lab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return cur;
+}
+__device__ __forceinline__ void lds_union(unsigned* lab, unsigned a, unsigned b) {
+    for (;;) {
+        unsigned ra = lds_find(lab, a), rb = lds_find(lab, b);
+        if (ra == rb) return;
+        if (ra < rb) { const unsigned q = ra; ra = rb; rb = q; }
+        const unsigned old = atomicMin(&lab[ra & 0x7fffffffu], rb);
+        if (old == ra) return;
+        a = old, b = rb;
     }
 }
+// Which links a chunk's pixels have to make, from candidate bits alone.  C / U: columns -1 .. 16 of the pixel's row
+// and of the row above as bits 0 .. 17.  Pixels of one horizontal run are one component already (and so are the
+// runs of the row above, by whoever owns that row), so a link that the left or right neighbour makes as well is
+// skipped: one link per pair of touching runs.  out[0] left (pixel 0 only), [1] up-left, [2] up, [3] up-right.
+__device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4]) {
+    const unsigned cand = (C >> 1) & 0xFFFFu;
+    const unsigned Lm = C & 0xFFFFu, Rm = (C >> 2) & 0xFFFFu, ULm = U & 0xFFFFu, UCm = (U >> 1) & 0xFFFFu, URm = (U >> 2) & 0xFFFFu;
+    out[0] = cand & Lm & 1u;
+    out[1] = cand & ~UCm & ULm & ~Lm;
+    out[2] = cand & UCm & ~(Lm & ULm);
+    out[3] = cand & ~UCm & URm & ~Rm;
+}
 
-// Wave-balanced union pass: a wave scans 64 16-pixel chunks (one 16-byte load per lane), appends the candidate
-// pixels to a wave-private LDS list, then the lanes share the list evenly -- edges cluster, so without this one
-// lane would walk all 16 candidates of a chunk alone.  Grid: (chunk groups of one frame, frame).
-constexpr int CCK = 1;        // groups per wave; 4 was slower (145 vs 122 us): it only lengthens each wave's chain of dependent atomics
-__global__ void __launch_bounds__(256) ccl_merge_fast(const uint8_t* __restrict__ map_all, int h, int w,
-                                                      unsigned* __restrict__ labels_all) {
-    __shared__ unsigned list[4][1024];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = blockIdx.y;
-    const int cw = w >> 4;
-    const float rcw = 1.0f / (float)cw;
-    const unsigned total = (unsigned)(h * cw);
-    const unsigned c0 = (blockIdx.x * 4u + (unsigned)wid) * (64u * CCK);
-    if (c0 >= total) return;
+__global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,
+                                                       unsigned* __restrict__ labels_all) {
+    __shared__ unsigned lab[CT_PX];               // local label: pixel index inside the tile (row * 256 + column), bit 31 = weak
+    __shared__ unsigned cm[CT_NCH];               // per 16-pixel chunk: candidate bits | strong bits << 16
+    const int tid = threadIdx.x, x0 = blockIdx.x * CT_C, y0 = blockIdx.y * CT_R, s = blockIdx.z;
     const uint8_t* m = map_all + (size_t)s * h * w;
-    unsigned* lab = labels_all + (size_t)s * h * w;
-    uint4 v[CCK];
+    unsigned* glab = labels_all + (size_t)s * h * w;
+    constexpr int Q = CT_NCH / 256;
+    unsigned candq[Q];
+    bool any = false;
 #pragma unroll
-    for (int g = 0; g < CCK; ++g) {
-        const unsigned ci = c0 + (unsigned)(g * 64 + lane);
-        v[g] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        if (ci < total) v[g] = *reinterpret_cast<const uint4*>(m + (size_t)ci * 16);      // w % 16 == 0: chunk ci starts at byte 16 ci
-    }
+    for (int q = 0; q < Q; ++q) {
+        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
+        const int y = y0 + r, x = x0 + cc * 16;
+        uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (y < h && x < w) v = *reinterpret_cast<const uint4*>(m + (size_t)y * w + x);          // w % 16 == 0
+        unsigned cand = 0, strong = 0;
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
 #pragma unroll
-    for (int g = 0; g < CCK; ++g) {
-        unsigned cand = 0;                               // bit k: pixel k of this lane's chunk is a candidate
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v[g]);
+        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
+        candq[q] = cand;
+        cm[c] = cand | strong << 16;
+        any = any || cand != 0;
+        // own label, or the smallest label of the horizontal run inside the chunk (first strong pixel, else first pixel)
+        unsigned rest = cand;
+        while (rest) {
+            const int a = __ffs((int)rest) - 1;
+            const unsigned run = rest & ~(rest + (1u << a));
+            rest &= ~run;
+            const unsigned sr = strong & run;
+            const int rp = sr ? __ffs((int)sr) - 1 : a;
+            const unsigned rep = (unsigned)(c * 16 + rp) | (sr ? 0u : 0x80000000u);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k;
-        const int mine = __popc(cand);
-        if (__ballot(mine != 0) == 0ull) continue;
-        int off = mine;                                  // exclusive prefix of `mine` over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(off, d, 64);
-            if (lane >= d) off += o;
+            for (int k = 0; k < 16; ++k)
+                if ((run >> k) & 1u) lab[c * 16 + k] = rep;
         }
-        const int n = __shfl(off, 63, 64);
-        off -= mine;
-        unsigned bits = cand;
+    }
+    if (__syncthreads_or(any ? 1 : 0) == 0) return;               // no candidate in the tile: the labels are never read
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const unsigned cand = candq[q];
+        if (!cand) continue;
+        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
+        // neighbours outside the tile count as absent here: the border pass makes those links
+        const unsigned Lb = cc > 0 ? (cm[c - 1] >> 15) & 1u : 0u, Rb = cc < CT_CH - 1 ? cm[c + 1] & 1u : 0u;
+        unsigned ucand = 0, ULb = 0, URb = 0;
+        if (r > 0) {
+            ucand = cm[c - CT_CH] & 0xFFFFu;
+            ULb = cc > 0 ? (cm[c - CT_CH - 1] >> 15) & 1u : 0u;
+            URb = cc < CT_CH - 1 ? cm[c - CT_CH + 1] & 1u : 0u;
+        }
+        unsigned link[4];
+        ccl_links((cand << 1) | Lb | (Rb << 17), (ucand << 1) | ULb | (URb << 17), link);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned bits = link[t];
+            while (bits) {
+                const int k = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const unsigned me = (unsigned)(c * 16 + k);
+                lds_union(lab, me, t == 0 ? me - 1u : me - (unsigned)CT_C + (unsigned)t - 2u);
+            }
+        }
+    }
+    __syncthreads();
+    // every candidate -> the global label of its tile-local root
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        unsigned bits = candq[q];
+        if (!bits) continue;
+        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
+        unsigned* out = glab + (size_t)(y0 + r) * w + x0 + cc * 16;
         while (bits) {
             const int k = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            // (pixel in chunk, lane of the chunk, left / right neighbour inside the chunk is a candidate)
-            list[wid][off++] = (unsigned)k | (unsigned)lane << 4 |
-                               (k > 0 ? ((cand >> (k - 1)) & 1u) << 10 : 0u) | (k < 15 ? ((cand >> (k + 1)) & 1u) << 11 : 0u);
+            const unsigned root = lds_find(lab, (unsigned)(c * 16 + k));
+            const unsigned rl = root & 0x7fffffffu;
+            out[k] = (unsigned)((y0 + (int)(rl >> 8)) * w + x0 + (int)(rl & 255u)) | (root & 0x80000000u);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        for (int i = lane; i < n; i += 64) {
-            const unsigned e = list[wid][i];
-            int yj, xb;
-            chunk_xy(c0 + (unsigned)(g * 64) + ((e >> 4) & 63u), cw, rcw, yj, xb);
-            const int x = xb + (int)(e & 15u);
-            const unsigned me = (unsigned)(yj * w + x);
-            // Links to the row above, once per pair of runs: pixels of one run are one component already (and so are
-            // the runs up there, by whoever owns that row), so a link that the left or right neighbour of this pixel
-            // makes as well is skipped.  L / R: the neighbour in this row is a candidate.
-            const unsigned k = e & 15u;
-            const uint8_t* row = m + (size_t)yj * w;
-            const bool L = k > 0 ? (e >> 10) & 1u : (x > 0 && row[x - 1] != 1);
-            const bool R = k < 15 ? (e >> 11) & 1u : (x + 1 < w && row[x + 1] != 1);
-            if (k == 0 && L) uf_union(lab, me, me - 1);                       // inside a chunk the run is linked already
-            if (yj > 0) {
-                const uint8_t* upr = row - w;
-                const bool UL = x > 0 && upr[x - 1] != 1, UC = upr[x] != 1, UR = x + 1 < w && upr[x + 1] != 1;
-                const unsigned up = (unsigned)((yj - 1) * w + x);
-                if (UC) {
-                    if (!(L && UL)) uf_union(lab, me, up);
-                } else {
-                    if (UL && !L) uf_union(lab, me, up - 1);
-                    if (UR && !R) uf_union(lab, me, up + 1);
-                }
-            }
+    }
+}
+
+// Links across tile borders, with global unions.  blockIdx.y < nbh: the horizontal border above row (blockIdx.y+1)*16,
+// one thread per column; else the vertical border left of column (blockIdx.y-nbh+1)*256, one thread per row.  Same
+// skipping rules as inside the tiles, here with every neighbour's true candidate bit.
+__global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restrict__ map_all, int h, int w, int nbh,
+                                                         unsigned* __restrict__ labels_all) {
+    const int s = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t* m = map_all + (size_t)s * h * w;
+    unsigned* lab = labels_all + (size_t)s * h * w;
+    auto cand = [&](int y, int x) { return y >= 0 && x >= 0 && x < w && m[(size_t)y * w + x] != 1; };
+    if ((int)blockIdx.y < nbh) {
+        const int y = ((int)blockIdx.y + 1) * CT_R, x = i;
+        if (x >= w || !cand(y, x)) return;
+        const bool L = cand(y, x - 1), R = cand(y, x + 1), UL = cand(y - 1, x - 1), UC = cand(y - 1, x), UR = cand(y - 1, x + 1);
+        const unsigned me = (unsigned)(y * w + x), up = me - (unsigned)w;
+        if (UC) {
+            if (!(L && UL)) uf_union(lab, me, up);
+        } else {
+            if (UL && !L) uf_union(lab, me, up - 1u);
+            if (UR && !R) uf_union(lab, me, up + 1u);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");      // the list is reused by the next group
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    } else {
+        const int x = ((int)blockIdx.y - nbh + 1) * CT_C, y = i;       // A = (y, x), B = (y, x - 1) on the other side
+        if (y >= h) return;
+        const bool A = cand(y, x), B = cand(y, x - 1);
+        const unsigned a = (unsigned)(y * w + x);
+        if (A && B) uf_union(lab, a, a - 1u);
+        if (y % CT_R == 0) return;                                        // the horizontal pass owns the links to the row above
+        if (A && !B && cand(y - 1, x - 1) && !cand(y - 1, x)) uf_union(lab, a, a - (unsigned)w - 1u);       // A's up-left
+        if (B && !A && cand(y - 1, x) && !cand(y - 1, x - 1)) uf_union(lab, a - 1u, a - (unsigned)w);       // B's up-right
     }
 }
 
@@ -1947,9 +1987,12 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         AV_LAUNCH_CHECK();
         const unsigned fchunks = (unsigned)h * (unsigned)(w >> 4);                 // 16-pixel chunks of one frame
         if (fastp) {
-            hipLaunchKernelGGL(ccl_runs_fast, dim3((fchunks + 255) / 256, n_streams), dim3(256), 0, st, map, h, w, labels);
-            hipLaunchKernelGGL(ccl_merge_fast, dim3((fchunks + 256 * CCK - 1) / (256 * CCK), n_streams), dim3(256), 0, st, map, h, w,
-                               labels);
+            hipLaunchKernelGGL(ccl_tile_kernel, dim3((w + CT_C - 1) / CT_C, (h + CT_R - 1) / CT_R, n_streams), dim3(256), 0, st, map,
+                               h, w, labels);
+            const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
+            if (nbh + nbv > 0)
+                hipLaunchKernelGGL(ccl_border_kernel, dim3((span + 255) / 256, nbh + nbv, n_streams), dim3(256), 0, st, map, h, w,
+                                   nbh, labels);
         } else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
         AV_LAUNCH_CHECK();
         Roi roi;
