@@ -47,6 +47,10 @@ struct ConvArgs {
     int act, npix;                                            // npix = B*Ho*Wo
 };
 
+// SiLU with v_rcp_f32 (1 ulp) instead of an IEEE divide: the result is rounded to bf16 anyway, and the epilogue of
+// these small convolutions is as long as their K loop.
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 template <int MT, int NT>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
             float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
             if (a.act)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.0f + __expf(-v[q]));              // SiLU
+                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
             if (a.res) {
                 const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
                 v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
@@ -190,6 +194,21 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             wv[k] = (w_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(a.wgt + (size_t)w_g[k] + c0) : make_uint4(0, 0, 0, 0);
     };
     gload(0);
+    // bias and residual of this lane's outputs are fetched now: in the epilogue their latency would be exposed
+    float4 bsv[MT];
+    ushort4 resv[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ch = ch_base + mt * 16 + 4 * h;
+        bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            resv[mt][nt] = make_ushort4(0, 0, 0, 0);
+            const int oy = oy0 + 2 * wave + nt, ox = ox0 + l15;
+            if (a.res && oy < a.Ho && ox < a.Wo)
+                resv[mt][nt] = *reinterpret_cast<const ushort4*>(a.res + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.res_cs + a.res_coff + ch);
+        }
+    }
     for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
         __syncthreads();                        // every wave is done reading the previous chunk
 #pragma unroll
@@ -219,7 +238,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ch = ch_base + mt * 16 + 4 * h;
-        const float4 bs = *reinterpret_cast<const float4*>(a.bias + ch);
+        const float4 bs = bsv[mt];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int oy = oy0 + 2 * wave + nt, ox = ox0 + l15;
@@ -228,9 +247,9 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
             if (a.act)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.0f + __expf(-v[q]));
+                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
             if (a.res) {
-                const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
+                const ushort4 rr = resv[mt][nt];
                 v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
             }
             if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
