@@ -58,6 +58,8 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
     return p;
 }
+// one reflection, branch-free: p in [-(n-1), 2n-2], n >= 2 (the streaming kernels: rows -2 .. h+1 of frames with h >= 8)
+__device__ __forceinline__ int reflect101_once(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
 __device__ __forceinline__ int clampi(int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); }
 
 // ---- L1: gray + blur + histogram -----------------------------------------------------------------------
@@ -449,6 +451,7 @@ __device__ __forceinline__ unsigned dpp_next_u32(unsigned v) {      // value of 
 
 constexpr int SW = 248;                 // output columns per wave strip (62 lanes x 4)
 constexpr int SROWS = 48;               // output rows per wave
+constexpr int SPF = 3;                  // rows fetched ahead
 
 __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __restrict__ bgr, int h, int w,
                                                              uint8_t* __restrict__ blur, unsigned* __restrict__ hist) {
@@ -467,16 +470,34 @@ __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __re
         // horizontal pass results of the last five rows, two u16 pairs per row (pixels 0,1 | 2,3)
         unsigned ra[5], rb[5];
         const int y_end = (yb + SROWS < h ? yb + SROWS : h);
+        // A wave consumes one 768-byte row segment per trip and nothing else hides the load behind it: keep the next
+        // SPF rows in flight.  Unconditional loads (halo lanes and rows past the end re-read a valid address), so the
+        // compiler can count them and wait for exactly the oldest one.
+        unsigned fa[SPF], fb[SPF], fc[SPF];
+        const uint8_t* col = img + (size_t)(xin ? x : 0) * 3;
+        const unsigned pitch = (unsigned)w * 3u;
+        auto fetch = [&](int yy, unsigned& a, unsigned& b, unsigned& c) {
+            const int ys = reflect101_once(yy < y_end + 1 ? yy : y_end + 1, h);
+            const unsigned* p = reinterpret_cast<const unsigned*>(col + (size_t)ys * pitch);
+            a = p[0], b = p[1], c = p[2];
+        };
+#pragma unroll
+        for (int q = 0; q < SPF; ++q) fetch(yb - 2 + q, fa[q], fb[q], fc[q]);
         for (int yy = yb - 2; yy < y_end + 2; ++yy) {
-            const int ys = reflect101(yy, h);
             unsigned g = 0;                                     // 4 gray bytes, pixel 0 in the low byte
+            const unsigned a = fa[0], b = fb[0], c = fc[0];     // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+#pragma unroll
+            for (int q = 0; q + 1 < SPF; ++q) fa[q] = fa[q + 1], fb[q] = fb[q + 1], fc[q] = fc[q + 1];
+            fetch(yy + SPF, fa[SPF - 1], fb[SPF - 1], fc[SPF - 1]);
             if (xin) {
-                const unsigned* p = reinterpret_cast<const unsigned*>(img + ((size_t)ys * w + x) * 3);
-                const unsigned a = p[0], b = p[1], c = p[2];    // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                const unsigned g0 = (1868u * (a & 255u) + 9617u * ((a >> 8) & 255u) + 4899u * ((a >> 16) & 255u) + 8192u) >> 14;
-                const unsigned g1 = (1868u * (a >> 24) + 9617u * (b & 255u) + 4899u * ((b >> 8) & 255u) + 8192u) >> 14;
-                const unsigned g2 = (1868u * ((b >> 16) & 255u) + 9617u * (b >> 24) + 4899u * (c & 255u) + 8192u) >> 14;
-                const unsigned g3 = (1868u * ((c >> 8) & 255u) + 9617u * ((c >> 16) & 255u) + 4899u * (c >> 24) + 8192u) >> 14;
+                // 24-bit multiply-adds (full rate; the 32-bit ones hipcc picks otherwise run at a quarter of it)
+                auto gray = [](unsigned bb, unsigned gg, unsigned rr) {
+                    return ((unsigned)__umul24(1868u, bb) + (unsigned)__umul24(9617u, gg) + (unsigned)__umul24(4899u, rr) + 8192u) >> 14;
+                };
+                const unsigned g0 = gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+                const unsigned g1 = gray(a >> 24, b & 255u, (b >> 8) & 255u);
+                const unsigned g2 = gray((b >> 16) & 255u, b >> 24, c & 255u);
+                const unsigned g3 = gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
                 g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
             }
             unsigned gp = dpp_prev_u32(g), gn = dpp_next_u32(g);
@@ -542,11 +563,20 @@ __global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restric
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) gxm[q][k] = gym[q][k] = 0;
+    unsigned fr[SPF];                               // the next SPF rows, in flight (see gray_blur_hist_stream)
+    const uint8_t* col = img + (xin ? x : 0);
+    auto fetch = [&](int yy) {
+        const int ys = clampi(yy < y_end + 1 ? yy : y_end + 1, h);
+        return *reinterpret_cast<const unsigned*>(col + (size_t)ys * (unsigned)w);
+    };
+#pragma unroll
+    for (int q = 0; q < SPF; ++q) fr[q] = fetch(yb - 2 + q);
     for (int yy = yb - 2; yy < y_end + 2; ++yy) {
-        // ---- stage 1: load blurred row yy (replicate at the borders) ------------------------------------
-        const int ys = clampi(yy, h);
-        unsigned c = 0;
-        if (xin) c = *reinterpret_cast<const unsigned*>(img + (size_t)ys * w + x);
+        // ---- stage 1: blurred row yy (replicate at the borders) -----------------------------------------
+        const unsigned c = xin ? fr[0] : 0u;
+#pragma unroll
+        for (int q = 0; q + 1 < SPF; ++q) fr[q] = fr[q + 1];
+        fr[SPF - 1] = fetch(yy + SPF);
         unsigned lft = dpp_prev_u32(c) >> 24, rgt = dpp_next_u32(c) & 255u;
         if (x == 0) lft = c & 255u;
         if (x + 4 == w) rgt = c >> 24;
@@ -604,7 +634,7 @@ __global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restric
                 if (m > lo) {
                     const int xs = gxm[0][k], ysg = gym[0][k];
                     const int ax = abs(xs), ay = abs(ysg) << 15;
-                    const int tg22x = ax * 13573;
+                    const int tg22x = __mul24(ax, 13573);                    // |gx| <= 1020
                     bool is_max;
                     if (ay < tg22x) is_max = m > mm[1][k] && m >= mm[1][k + 2];
                     else {
