@@ -459,8 +459,11 @@ __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __re
     const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < 16 * 256; i += 256) lh[i] = 0;
     __syncthreads();
-    const int strip = blockIdx.x, x0 = strip * SW - 4;          // column of lane 0's first pixel (halo lane)
-    const int yb = (blockIdx.y * 4 + wid) * SROWS;              // first output row of this wave
+    // the four waves of a workgroup take neighbouring strips of the same band of rows (strip fastest over the grid):
+    // together they read a contiguous piece of every row
+    const int nstrips = (w + SW - 1) / SW, wv = blockIdx.x * 4 + wid;
+    const int strip = wv % nstrips, x0 = strip * SW - 4;        // column of lane 0's first pixel (halo lane)
+    const int yb = (wv / nstrips) * SROWS;                      // first output row of this wave
     const int x = x0 + 4 * lane;                                // this lane's columns x .. x+3
     const bool xin = x >= 0 && x + 4 <= w;                      // chunk fully inside the image (w % 4 == 0)
     const bool out_lane = lane >= 1 && lane <= 62 && xin;
@@ -538,8 +541,9 @@ __global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restric
                                                         const double* __restrict__ thr, uint8_t* __restrict__ map,
                                                         unsigned* __restrict__ labels) {
     const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int strip = blockIdx.x, x0 = strip * SW - 4;
-    const int yb = (blockIdx.y * 4 + wid) * SROWS;
+    const int nstrips = (w + SW - 1) / SW, wv = blockIdx.x * 4 + wid;       // strip fastest, as in gray_blur_hist_stream
+    const int strip = wv % nstrips, x0 = strip * SW - 4;
+    const int yb = (wv / nstrips) * SROWS;
     if (yb >= h) return;
     const int x = x0 + 4 * lane;
     const bool xin = x >= 0 && x + 4 <= w;
@@ -2004,7 +2008,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
     const bool streamp = (w % 4 == 0) && w >= 8 && (((size_t)bgr | (size_t)workspace) & 15) == 0 && !(stages & 4);
     if (!(stages & 16)) {                                          // bit 4: Hough + fit only, on the point lists already in the workspace
-        const dim3 sgrid((w + SW - 1) / SW, (h + 4 * SROWS - 1) / (4 * SROWS), n_streams);
+        const dim3 sgrid((((w + SW - 1) / SW) * ((h + SROWS - 1) / SROWS) + 3) / 4, 1, n_streams);      // waves = strips x bands
         if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
         else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
         else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
