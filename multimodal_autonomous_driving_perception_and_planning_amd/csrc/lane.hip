@@ -452,6 +452,7 @@ __device__ __forceinline__ unsigned dpp_next_u32(unsigned v) {      // value of 
 constexpr int SW = 248;                 // output columns per wave strip (62 lanes x 4)
 constexpr int SROWS = 48;               // output rows per wave
 constexpr int SPF = 3;                  // rows fetched ahead
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __restrict__ bgr, int h, int w,
                                                              uint8_t* __restrict__ blur, unsigned* __restrict__ hist) {
@@ -493,14 +494,17 @@ __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __re
             for (int q = 0; q + 1 < SPF; ++q) fa[q] = fa[q + 1], fb[q] = fb[q + 1], fc[q] = fc[q + 1];
             fetch(yy + SPF, fa[SPF - 1], fb[SPF - 1], fc[SPF - 1]);
             if (xin) {
-                // 24-bit multiply-adds (full rate; the 32-bit ones hipcc picks otherwise run at a quarter of it)
-                auto gray = [](unsigned bb, unsigned gg, unsigned rr) {
-                    return ((unsigned)__umul24(1868u, bb) + (unsigned)__umul24(9617u, gg) + (unsigned)__umul24(4899u, rr) + 8192u) >> 14;
+                // gray = (1868 B + 9617 G + 4899 R + 8192) >> 14: B and G spread to a u16 pair by one byte permute, one
+                // dot2 against (1868, 9617), one 24-bit multiply-add for R (all full rate)
+                const u16x2_t wbg = {1868, 9617};
+                auto gray = [&](unsigned bg_pair, unsigned rr) {
+                    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, bg_pair), wbg, (unsigned)__umul24(4899u, rr) + 8192u, false) >> 14;
                 };
-                const unsigned g0 = gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
-                const unsigned g1 = gray(a >> 24, b & 255u, (b >> 8) & 255u);
-                const unsigned g2 = gray((b >> 16) & 255u, b >> 24, c & 255u);
-                const unsigned g3 = gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+                // v_perm_b32 selectors: bytes 0-3 = second operand, 4-7 = first operand, 0x0C = zero
+                const unsigned g0 = gray(__builtin_amdgcn_perm(0u, a, 0x0C010C00u), (a >> 16) & 255u);          // B0 G0 | R0
+                const unsigned g1 = gray(__builtin_amdgcn_perm(b, a, 0x0C040C03u), (b >> 8) & 255u);           // B1 (a.3) G1 (b.0) | R1
+                const unsigned g2 = gray(__builtin_amdgcn_perm(0u, b, 0x0C030C02u), c & 255u);                  // B2 G2 | R2
+                const unsigned g3 = gray(__builtin_amdgcn_perm(0u, c, 0x0C020C01u), c >> 24);                   // B3 G3 | R3
                 g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
             }
             unsigned gp = dpp_prev_u32(g), gn = dpp_next_u32(g);
@@ -539,7 +543,6 @@ __global__ void __launch_bounds__(256) gray_blur_hist_stream(const uint8_t* __re
 
 // packed 16-bit pairs in a 32-bit register (v_pk_*_i16 / _u16)
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2_t, a) - __builtin_bit_cast(s16x2_t, b));
 }
