@@ -257,7 +257,8 @@ int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors);     
 int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float conf_thres, float iou_thres,
                     int max_det, int32_t* det_n, float* det_box, float* det_conf, int32_t* det_cls);
 /* Test hook: device pointer + geometry of an intermediate NHWC tensor (bf16; ids = yolov8.yaml layer
- * numbers, 0 = network input; 100+2i / 101+2i = float32 box / class logits of level i). */
+ * numbers, 0 = network input: RGB in 4-channel pixels inside a one-pixel frame of zeros, [H+2][W+2]; 100+2i / 101+2i =
+ * float32 box / class logits of level i). */
 int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff);
 
 /* ---- T1: maneuver tags ------------------------------------------------------

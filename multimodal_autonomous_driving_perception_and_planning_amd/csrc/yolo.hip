@@ -260,7 +260,39 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     }
 }
 
-// letterbox + bilinear resize + BGR->RGB + /255 -> NHWC8 bf16 (channels 3..7 zero)
+// Stem: 3x3 stride-2 convolution 3 -> 16 channels on the framed NHWC4 input.  K is laid out as [ky][kx 0..3][c 0..3]
+// (kx = 3 and c = 3 carry zero weights; 48 -> 64): an 8-element B operand is then two horizontally adjacent input
+// pixels = one aligned 16-byte load (the frame makes column 2*ox + kx even and every load in bounds), and the whole
+// receptive field is two MFMA steps.  Half the bytes of the 8-channel layout on both sides of the kernel.
+__global__ void __launch_bounds__(256) stem_conv_kernel(ConvArgs a, int npix) {
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, h = lane >> 4;
+    const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(a.wgt + l15 * 64 + 8 * h);
+    const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(a.wgt + l15 * 64 + 32 + 8 * h);
+    const float4 bs = *reinterpret_cast<const float4*>(a.bias + 4 * h);
+    const int pitch = (a.W + 2) * 4, hw = a.Ho * a.Wo;                           // elements per framed input row
+    // k-step 0: group h = (ky, kx) = (h >> 1, 2 (h & 1)); k-step 1: ky = 2, groups 2 and 3 have zero weights
+    const int off0 = (h >> 1) * pitch + (h & 1) * 8, off1 = 2 * pitch + (h & 1) * 8;
+    constexpr int TPV = 4;                                                        // 16-pixel tiles per wave
+    const int tile0 = (blockIdx.x * 4 + (tid >> 6)) * TPV;
+#pragma unroll
+    for (int i = 0; i < TPV; ++i) {
+        const int p = (tile0 + i) * 16 + l15;
+        const int pc = p < npix ? p : npix - 1;
+        const int n = pc / hw, r = pc - n * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
+        const bf16_t* base = a.in + ((size_t)(n * (a.H + 2) + 2 * oy) * (a.W + 2) + 2 * ox) * 4;
+        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(base + off0);
+        const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(base + off1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, acc, 0, 0, 0);
+        if (p < npix)
+            *reinterpret_cast<ushort4*>(a.out + (size_t)p * a.out_cs + a.out_coff + 4 * h) =
+                make_ushort4(f2bf(silu(acc[0] + bs.x)), f2bf(silu(acc[1] + bs.y)), f2bf(silu(acc[2] + bs.z)), f2bf(silu(acc[3] + bs.w)));
+    }
+}
+
+// letterbox + bilinear resize + BGR->RGB + /255 -> NHWC4 bf16 (channel 3 zero) inside a one-pixel frame of zeros:
+// [B][H+2][W+2][4], the frame is the stem convolution's padding and is never written
 __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
                                   int top, int left, bf16_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,8 +315,8 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h,
             c[q] = floorf(ta * (1.f - wy) + tb * wy + 0.5f);
         }
     }
-    bf16_t o[8] = {f2bf(c[2] / 255.f), f2bf(c[1] / 255.f), f2bf(c[0] / 255.f), 0, 0, 0, 0, 0};   // RGB
-    *reinterpret_cast<uint4*>(out + (size_t)i * 8) = *reinterpret_cast<const uint4*>(o);
+    bf16_t o[4] = {f2bf(c[2] / 255.f), f2bf(c[1] / 255.f), f2bf(c[0] / 255.f), 0};   // RGB
+    *reinterpret_cast<uint2*>(out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4) = *reinterpret_cast<const uint2*>(o);
 }
 
 __global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
@@ -601,7 +633,7 @@ int new_buf(Yolo& y, int H, int W, int C) {
 
 // consumes one conv's parameters, folds BN, uploads bf16 [cout][kpad] + f32 bias, appends the op
 bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* out32, int out32_cs, const Slice* res) {
-    const int cin_real = in.c == 8 && y.ops.empty() ? 3 : in.c;     // the network input is RGB padded to 8 channels
+    const int cin_real = in.c;
     const int cin = in.c, cout = out.c, taps = k * k;
     const int kreal = taps * cin, kpad = (kreal + 31) & ~31;
     const size_t nw = (size_t)cout * cin_real * taps, nb = bn_act ? 4 * (size_t)cout : (size_t)cout;
@@ -642,6 +674,42 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     if (res) a.res = y.bufs[res->buf].p, a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
     a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
     op.mt = (cout % 64 == 0) ? 4 : ((cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1));
+    y.ops.push_back(op);
+    return true;
+}
+
+// the stem's parameters (Conv 3 -> 16, k3 s2, BN, SiLU) packed for stem_conv_kernel: bf16 [16][64], k = ky*16 + kx*4 + c
+bool add_stem(Yolo& y, Slice in, Slice out) {
+    const int cout = 16, cin_real = 3, taps = 9;
+    const size_t nw = (size_t)cout * cin_real * taps, nb = 4 * (size_t)cout;
+    if (out.c != cout || y.wpos + nw + nb > y.wtotal) return false;
+    const float* w = y.wsrc + y.wpos;
+    const float* bp = w + nw;
+    y.wpos += nw + nb;
+    std::vector<bf16_t> wb((size_t)cout * 64, 0);
+    std::vector<float> bias(cout);
+    for (int co = 0; co < cout; ++co) {
+        const float g = bp[co], be = bp[cout + co], mu = bp[2 * cout + co], var = bp[3 * cout + co];
+        const float scale = g / std::sqrt(var + 1e-3f);
+        bias[co] = be - mu * scale;
+        for (int ci = 0; ci < cin_real; ++ci)
+            for (int t = 0; t < taps; ++t)
+                wb[(size_t)co * 64 + (t / 3) * 16 + (t % 3) * 4 + ci] = f2bf(w[((size_t)co * cin_real + ci) * taps + t] * scale);
+    }
+    bf16_t* dw;
+    float* db;
+    if (!dev_alloc(y, (void**)&dw, wb.size() * 2) || !dev_alloc(y, (void**)&db, bias.size() * 4)) return false;
+    (void)hipMemcpy(dw, wb.data(), wb.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+    Yolo::Op op{};
+    op.kind = 4;
+    ConvArgs& a = op.ca;
+    a.in = y.bufs[in.buf].p, a.in_cs = 4, a.in_coff = 0, a.cin = 4, a.H = y.H, a.W = y.W;      // H, W: without the frame
+    a.wgt = dw, a.bias = db, a.kpad = 64, a.kreal = 27, a.ksz = 3, a.stride = 2;
+    a.Ho = (y.H - 1) / 2 + 1, a.Wo = (y.W - 1) / 2 + 1;
+    a.out = y.bufs[out.buf].p, a.out32 = nullptr, a.out_cs = y.bufs[out.buf].C, a.out_coff = out.coff;
+    a.cout = cout, a.res = nullptr, a.res_cs = 0, a.res_coff = 0, a.act = 1, a.npix = y.B * a.Ho * a.Wo;
+    op.mt = 1;
     y.ops.push_back(op);
     return true;
 }
@@ -714,7 +782,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     bool ok = true;
     const int H = y.H, W = y.W;
     auto nb = [&](int hh, int ww, int c) { const int b = new_buf(y, hh, ww, c); ok = ok && b >= 0; return b; };
-    const int x0 = nb(H, W, 8), b0 = nb(H / 2, W / 2, 16), b1 = nb(H / 4, W / 4, 32), b2 = nb(H / 4, W / 4, 32);
+    const int x0 = nb(H + 2, W + 2, 4), b0 = nb(H / 2, W / 2, 16), b1 = nb(H / 4, W / 4, 32), b2 = nb(H / 4, W / 4, 32);
     const int cat14 = nb(H / 8, W / 8, 192), cat11 = nb(H / 16, W / 16, 384), cat20 = nb(H / 32, W / 32, 384);
     const int cat17 = nb(H / 16, W / 16, 192);
     const int b3 = nb(H / 8, W / 8, 64), b5 = nb(H / 16, W / 16, 128), b7 = nb(H / 32, W / 32, 256), b8 = nb(H / 32, W / 32, 256);
@@ -723,7 +791,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     (void)d16;
     if (!ok) { av_yolo_destroy(h); av_set_error("av_yolo_create: device allocation failed"); return AV_ENOMEM; }
 #define CV(...) ok = ok && add_conv(y, __VA_ARGS__)
-    CV(Slice{x0, 0, 8}, Slice{b0, 0, 16}, 3, 2, true, nullptr, 0, nullptr);                       // 0
+    ok = ok && add_stem(y, Slice{x0, 0, 4}, Slice{b0, 0, 16});                                    // 0
     CV(Slice{b0, 0, 16}, Slice{b1, 0, 32}, 3, 2, true, nullptr, 0, nullptr);                      // 1
     ok = ok && add_c2f(y, Slice{b1, 0, 32}, Slice{b2, 0, 32}, 1, true);                            // 2
     CV(Slice{b2, 0, 32}, Slice{b3, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                      // 3
@@ -773,7 +841,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     ok = ok && dev_alloc(y, (void**)&y.cbox, (size_t)batch * y.A * 16) && dev_alloc(y, (void**)&y.cconf, (size_t)batch * y.A * 4) &&
          dev_alloc(y, (void**)&y.ccls, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.sbox, (size_t)batch * y.A * 16) &&
          dev_alloc(y, (void**)&y.sidx, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.scount, (size_t)batch * 4);
-    y.named = {{0, Slice{x0, 0, 8}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
+    y.named = {{0, Slice{x0, 0, 3}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
                {6, Slice{cat11, 256, 128}}, {8, Slice{b8, 0, 256}}, {9, Slice{cat20, 128, 256}}, {12, Slice{cat17, 64, 128}},
                {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}};
     y.wsrc = nullptr;
@@ -848,7 +916,10 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
         }
         st = (y.side && op.lane) ? y.side : st_main;
-        if (op.kind == 0) {
+        if (op.kind == 4) {
+            const ConvArgs& a = op.ca;
+            hipLaunchKernelGGL(stem_conv_kernel, dim3((a.npix + 255) / 256), dim3(256), 0, st, a, a.npix);
+        } else if (op.kind == 0) {
             const ConvArgs& a = op.ca;
             // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
             // a partial 32-channel chunk is zero-filled) and for 1x1 with whole chunks; stride 2 and the rest stay direct

@@ -31,7 +31,9 @@ def _rel(a, b):
 def test_preprocess_and_feature_maps(setup):
     Y, R, frame, feats, model, _ = setup
     assert model.dims() == (384, 640, 5040)
-    x = model.tensor(0)[..., :3].transpose(2, 0, 1)
+    t0 = model.tensor(0)                       # RGB inside a one-pixel frame of zeros (the stem's padding)
+    assert t0.shape == (386, 642, 3) and not t0[0].any() and not t0[-1].any() and not t0[:, 0].any() and not t0[:, -1].any()
+    x = t0[1:-1, 1:-1].transpose(2, 0, 1)
     assert np.abs(x - R.preprocess(frame)).max() <= 2 ** -8          # bf16 rounding of values in [0,1]
     for tid, key in ((1, "l1"), (2, "l2"), (4, "l4"), (6, "l6"), (8, "l8"), (9, "l9"), (12, "l12"), (15, "p3"),
                      (18, "p4"), (21, "p5")):
