@@ -319,6 +319,46 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h,
     *reinterpret_cast<uint2*>(out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4) = *reinterpret_cast<const uint2*>(o);
 }
 
+// The same for frames that are exactly twice the letterboxed size (1280x720 -> 640x360): the bilinear taps of an
+// output pixel are a 2x2 block with weights 1/2 (sx = 2 xx + 0.5 exactly, so the generic kernel's floats come out the
+// same), a thread makes two output pixels from 12 contiguous bytes of two rows -- six dword loads instead of 24 byte
+// loads.  Needs w % 4 == 0, a 4-byte aligned frame pointer, even left padding and even nw.
+__global__ void preprocess2_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
+                                   int top, int left, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, W2 = W >> 1;
+    if (i >= B * H * W2) return;
+    const int n = i / (H * W2), r = i - n * H * W2, y = r / W2, x = (r - y * W2) * 2;
+    float c[2][3] = {{114.f, 114.f, 114.f}, {114.f, 114.f, 114.f}};
+    const int yy = y - top, xx = x - left;
+    if (yy >= 0 && yy < nh && xx >= 0 && xx < nw) {
+        const uint8_t* im = bgr + (size_t)n * h * w * 3;
+        const unsigned* r0 = reinterpret_cast<const unsigned*>(im + ((size_t)(2 * yy) * w + 2 * xx) * 3);
+        const unsigned* r1 = reinterpret_cast<const unsigned*>(im + ((size_t)(2 * yy + 1) * w + 2 * xx) * 3);
+        const unsigned a0 = r0[0], b0 = r0[1], c0 = r0[2], a1 = r1[0], b1 = r1[1], c1 = r1[2];
+        // bytes: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3
+        auto px = [](unsigned a, unsigned b, unsigned cc, int p, int q) -> float {
+            const int byte = p * 3 + q;
+            const unsigned word = byte < 4 ? a : (byte < 8 ? b : cc);
+            return (float)((word >> (8 * (byte & 3))) & 255u);
+        };
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float p00 = px(a0, b0, c0, 2 * o, q), p01 = px(a0, b0, c0, 2 * o + 1, q);
+                const float p10 = px(a1, b1, c1, 2 * o, q), p11 = px(a1, b1, c1, 2 * o + 1, q);
+                const float ta = p00 * (1.f - 0.5f) + p01 * 0.5f, tb = p10 * (1.f - 0.5f) + p11 * 0.5f;
+                c[o][q] = floorf(ta * (1.f - 0.5f) + tb * 0.5f + 0.5f);
+            }
+    }
+    bf16_t* dst = out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        bf16_t v[4] = {f2bf(c[o][2] / 255.f), f2bf(c[o][1] / 255.f), f2bf(c[o][0] / 255.f), 0};   // RGB
+        *reinterpret_cast<uint2*>(dst + o * 4) = *reinterpret_cast<const uint2*>(v);
+    }
+}
+
 __global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
                                 int H, int W, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,8 +945,14 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     const bool force_direct = getenv("AVHOT_CONV_DIRECT") != nullptr;      // tuning aid, read once per forward
     {
         const int n = B * y.H * y.W;
-        hipLaunchKernelGGL(preprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
-                           y.nw, y.top, y.left, y.bufs[0].p);
+        const bool twice = y.inH == 2 * y.nh && y.inW == 2 * y.nw && y.inW % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0 &&
+                           y.left % 2 == 0 && y.nw % 2 == 0 && y.W % 2 == 0 && !getenv("AVHOT_YOLO_GENERIC_PRE");
+        if (twice)
+            hipLaunchKernelGGL(preprocess2_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
+                               y.nw, y.top, y.left, y.bufs[0].p);
+        else
+            hipLaunchKernelGGL(preprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
+                               y.nw, y.top, y.left, y.bufs[0].p);
         AV_LAUNCH_CHECK();
     }
     for (size_t oi = 0; oi < y.ops.size(); ++oi) {

@@ -159,3 +159,16 @@ def test_perception_loop_step_matches_per_frame_paths(setup):
     loop2.synchronize()
     torch.cuda.synchronize()
     assert lanes_equal(2)
+
+
+def test_two_to_one_preprocess_equals_generic_kernel(setup, monkeypatch):
+    """1280x720 frames take the 2:1 letterbox kernel (two output pixels from 12 contiguous bytes of two rows); it must
+    write exactly what the generic bilinear kernel writes."""
+    Y, R, frame, feats, model, _ = setup
+    model.detect(frame)                        # other tests ran other frames through this model
+    fast = model.tensor(0).copy()
+    monkeypatch.setenv("AVHOT_YOLO_GENERIC_PRE", "1")
+    other = Y.YoloV8n("random:0")
+    other.detect(frame)
+    assert np.array_equal(other.tensor(0), fast)
+    other.close()
