@@ -4,18 +4,24 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 it is launched under torch.distributed.run, one rank per GPU (RCCL).
 
-A "step" is one window of the hot loop over the rank's streams: detect (simulated) -> track ->
-Kalman step -> plan for `window` consecutive frames of each of `streams` video streams, all inputs
-(ego measurements, detector counters) already resident in HBM.  value = frames/s over all ranks.
+Headline (default) = BASELINE config 4, the per-GPU share of config 5: 64 concurrent synthetic streams per GPU
+batched through detect (simulated) -> track -> Kalman step -> plan, one hipGraph replay per step, a step = one
+256-frame window of every stream, all inputs resident in HBM.  value = frames/s over all ranks.
 
-Workloads (BASELINE.json configs):
-  config2  1 stream  per GPU, 1280x720, simulated detection + IoU tracker + KF + 21-candidate planner
-  config4  64 streams per GPU, same stages (the per-GPU share of config5's 512 streams on 8 GPUs)
+At N = 1 the same JSON line carries, under "also", the other single-GPU configurations measured in the same process:
+  config4_w1   config 4 with window 1: one graph replay per TIME-STEP (64 frames per replay)
+  config3      YOLO-mode detector (MFMA convs) + Canny/Hough lane detector on device-generated 1280x720 frames
+  config2      1 stream, simulated detection (latency-bound: one dependent chain)
+  config2_w1   config 2 with window 1
+each with the per-stage kernel list (isolated HIP-event times on the launch stream, share of their sum, what bounds
+the stage, achieved vs peak) and the roofline of the stage that dominates that configuration's step.
+`cpu_baseline` legs are timed BEFORE the GPU is initialised (the nproc leg starts child processes).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,119 +29,428 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF
+N_CUS = 256
+PKG = "multimodal_autonomous_driving_perception_and_planning_amd"
+METRIC = "end-to-end frames/sec (1280x720 synthetic)"
+
+# algorithmic HBM bytes per stream-frame
+TRACKER_BYTES = 2 * 48 * 48 + 7 * 24        # read+write hot table rows (T=48) + detections (D=7)  = 4776
+KF_BYTES = 768
+SIMDET_BYTES = 228                           # det_n + 7 x (box 16 + cls 4 + conf 8) written
+LANE_BYTES_PER_PX = 7
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config4", choices=["config2", "config3", "config4"])
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default by workload)")
     ap.add_argument("--window", type=int, default=None, help="frames per stream per step")
-    ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None, help="replay the step as a captured hipGraph")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--no-also", action="store_true", help="headline configuration only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-allgather", action="store_true")
-    ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step (no one-step-late Hough half)")
+    ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
+                    help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
+    ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step")
     ap.add_argument("--taggers", action="store_true",
                     help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds):
-    """The CPU oracle ("port" of the reference's NumPy path) on a bounded sample of the same loop."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = checker; timed here as the reported baseline only).  No GPU call before or inside.
+# ---------------------------------------------------------------------------------------------------------------
+_CHILD = ("import sys; sys.path.insert(0, %r); from oracle.harness_ref import time_cpu_loop; "
+          "print(time_cpu_loop(int(sys.argv[1]), warmup=5))" % ROOT)
+
+
+def cpu_hot_loop(seconds):
+    """NumPy oracle of the simulated-detection loop: 1 process x 1 thread, then nproc independent processes."""
     from oracle.harness_ref import time_cpu_loop
     fps0 = time_cpu_loop(40, warmup=3)
     n = max(60, int(fps0 * seconds))
     fps = time_cpu_loop(n, warmup=5)
-    return {"value": round(fps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the single-stream 1280x720 simulated-detection loop (detect+track+KF+plan), "
-                      "NumPy oracle, 1 thread" % n}
+    out = {"value": round(fps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the single-stream 1280x720 simulated-detection loop (detect+track+KF+plan), "
+                     "NumPy oracle, 1 process x 1 thread" % n}
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    P = max(1, min(ncpu, 64))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD, str(n)], stdout=subprocess.PIPE, env=env) for _ in range(P)]
+    ok = 0
+    for p in procs:
+        o, _ = p.communicate()
+        ok += 1 if p.returncode == 0 and o.strip() else 0
+    el = time.perf_counter() - t0
+    if ok == P:
+        out["nproc"] = {"value": round(P * (n + 5) / el, 2), "unit": "frames/s", "cores": P, "cpus_visible": ncpu,
+                        "sample": "%d independent single-stream processes x %d frames, wall time incl. interpreter start" % (P, n + 5)}
+    return out
 
 
-MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF
+def cpu_pixel_path(seconds):
+    """Config 3 on the host: C lane oracle (1 thread) + PyTorch-CPU fp32 YOLOv8n-topology forward, decode and NMS."""
+    import numpy as np
+    import torch
+    from oracle import lane_ref, yolo_ref
+    frames = [lane_ref.synthetic_frame(720, 1280, s, 0) for s in range(4)]
+    lr = lane_ref.LaneRef()
+    lr.detect(frames[0])
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds * 0.4 or n < 4:
+        lr.detect(frames[n % 4])
+        n += 1
+    lane_ms = (time.perf_counter() - t0) / n * 1e3
+    net = yolo_ref.build_model(yolo_ref.random_params(0))
+    thr = torch.get_num_threads()
+
+    def one(fr):
+        with torch.no_grad():
+            x = torch.from_numpy(yolo_ref.preprocess(fr))[None]
+            f = net.features(x)
+            b, c, k = yolo_ref.decode(f["head"])
+            keep = yolo_ref.nms(b, c, k)
+            return yolo_ref.scale_boxes(b[keep], 720, 1280)
+    one(frames[0])
+    t0, m = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds * 0.6 or m < 3:
+        one(frames[m % 4])
+        m += 1
+    yolo_ms = (time.perf_counter() - t0) / m * 1e3
+    return {"value": round(1e3 / (lane_ms + yolo_ms), 3), "unit": "frames/s", "cores": thr, "kind": "port",
+            "lane_ms_per_frame": round(lane_ms, 2), "yolo_ms_per_frame": round(yolo_ms, 2),
+            "sample": "%d frames through oracle/c/lane_ref.c (1 thread) + %d frames through oracle/yolo_ref.py "
+                      "(PyTorch-CPU fp32, %d intra-op threads), 1280x720 synthetic" % (n, m, thr)}
 
 
-def bench_config3(a, world, rank, local):
-    """YOLO-mode detector (random-init YOLOv8n topology, bf16 MFMA convs) + lane detector on frames generated
-    on the device.  step = one frame of each of `streams` cameras."""
+# ---------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------
+class Events:
+    def __init__(self, L, nat, n):
+        self.L, self.nat = L, nat
+        self.ev = [[C.c_void_p(), C.c_void_p()] for _ in range(n)]
+        for e in self.ev:
+            nat.check(L.av_event_create(C.byref(e[0])))
+            nat.check(L.av_event_create(C.byref(e[1])))
+
+    def avg_ms(self):
+        ms, tot = C.c_float(), 0.0
+        for e in self.ev:
+            self.nat.check(self.L.av_event_elapsed_ms(e[0], e[1], C.byref(ms)))
+            tot += ms.value
+        return tot / len(self.ev)
+
+    def close(self):
+        for e in self.ev:
+            self.L.av_event_destroy(e[0])
+            self.L.av_event_destroy(e[1])
+
+
+def time_stage(L, nat, stream, fn, reps, sync):
+    """Average HIP-event time of fn() alone on `stream` (the stream it is launched on)."""
+    fn()
+    sync()
+    ev = Events(L, nat, reps)
+    for e in ev.ev:
+        nat.check(L.av_event_record(e[0], stream))
+        fn()
+        nat.check(L.av_event_record(e[1], stream))
+    sync()
+    ms = ev.avg_ms()
+    ev.close()
+    return ms
+
+
+def pmc_traffic(name, key, scale):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        try:
+            return int(json.load(open(p))[key] * scale)
+        except Exception:
+            return None
+    return None
+
+
+def pmc_value(name, key):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(key)
+        except Exception:
+            return None
+    return None
+
+
+def finish_kernel_list(ks):
+    tot = sum(k["avg_ms"] for k in ks)
+    for k in ks:
+        k["share_of_stage_sum"] = round(k["avg_ms"] / tot, 4)
+        k["avg_ms"] = round(k["avg_ms"], 5)
+    return ks
+
+
+def max_over_ranks(el, world):
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return el, [round(el * 1e3, 4)]
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    per = [float(x.item()) for x in allt]
+    return max(per), [round(p * 1e3, 4) for p in per]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs 2 / 4: simulated detection -> tracker || Kalman -> planner
+# ---------------------------------------------------------------------------------------------------------------
+def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_reps=10):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.distributed import TrackTableExchange
+    from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+
+    loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True)
+    L = nat.lib()
+    g0 = rank * S                                      # global stream ids of this rank
+    loop.reset(frame_offsets=[(g0 + s) * 17 for s in range(S)])   # SURVEY 8d config 4: offset s*17
+    # synthetic ego measurements: one seeded sequence per stream, re-used every window (input data only)
+    zlen = max(W, 64)
+    z = np.stack([np.asarray(generate_ego_motion(zlen, seed=g0 + s), np.float64)[:W] for s in range(S)])
+    loop.load_measurements(z)
+    xchg = None
+    if world > 1 and not a.no_allgather:
+        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame"))
+    h, s = loop.ctx.handle, loop._s
+    cross = xchg is not None or a.taggers     # somebody on the main stream reads the tracker's tables every step
+
+    def one_step():
+        if graph:
+            loop.step(graph=True)             # fork{detect; track} || {kf; plan}; join -- inside the graph
+        else:
+            # side stream: detect -> track; main: kf -> plan.  When the main stream reads the tracker's tables every
+            # step (exchange / interaction tagger) the side stream must first wait for the previous step's readers
+            if cross:
+                nat.check(L.av_fork(h, s))
+            loop.enqueue_detect(loop.ctx.side_stream)
+            loop.enqueue_track(loop.ctx.side_stream)
+            loop.enqueue_kf()
+            loop.enqueue_plan()
+            if a.taggers:
+                loop.enqueue_maneuver()
+            if cross:
+                nat.check(L.av_join(h, s))
+        if a.taggers:
+            if graph:
+                loop.enqueue_maneuver()
+            loop.enqueue_interactions()
+        if xchg is not None:
+            xchg.exchange()
+
+    def drain():
+        if not graph:
+            nat.check(L.av_join(h, s))       # main stream waits for the side stream's tail
+        loop.synchronize()
+        if xchg is not None:
+            xchg.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    el, per_rank_ms = max_over_ranks(el, world)
+
+    # the tracker's sticky overflow flag: a truncated table would silently drop births (parity lost)
+    hdr, _, _ = loop.tracker_tables()
+    if int(np.abs(hdr[:, 3]).max()) != 0:
+        raise RuntimeError("tracker table overflow (hdr[3] != 0): tcap %d too small for this run" % loop.tcap)
+
+    # per-stage kernel times, each stage alone on the launch stream
+    F = S * W
+    sync = loop.synchronize
+    ks = []
+    t_det = time_stage(L, nat, s, loop.enqueue_detect, stage_reps, sync)
+    t_trk = time_stage(L, nat, s, loop.enqueue_track, stage_reps, sync)
+    t_kf = time_stage(L, nat, s, loop.enqueue_kf, stage_reps, sync)
+    t_pl = time_stage(L, nat, s, loop.enqueue_plan, stage_reps, sync)
+    pb = loop.planner_bytes_per_state() * F
+
+    def hbm(nbytes, ms):
+        return round(nbytes / (ms * 1e-3) / 1e9, 2)
+    ks.append({"kernel": "tracker_kernel", "stage": "track", "branch": "side", "avg_ms": t_trk, "bound": "latency",
+               "why": "one workgroup per stream walks its frames in order (frame t+1 needs frame t's table)",
+               "cus_occupied": min(S, N_CUS), "us_per_frame_per_stream": round(t_trk * 1e3 / W, 3),
+               "bytes_per_launch": TRACKER_BYTES * F, "achieved": hbm(TRACKER_BYTES * F, t_trk), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(hbm(TRACKER_BYTES * F, t_trk) / HBM_PEAK_GBS, 5)})
+    ks.append({"kernel": "planner_wave_kernel", "stage": "plan", "branch": "main", "avg_ms": t_pl,
+               "bound": "hbm" if F >= 4096 else "latency", "bytes_per_launch": pb, "achieved": hbm(pb, t_pl),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm(pb, t_pl) / HBM_PEAK_GBS, 4),
+               "traffic": pmc_traffic("planner_pmc.json", "hbm_bytes_per_state", F)})
+    ks.append({"kernel": "kf_axis_kernel", "stage": "kf", "branch": "main", "avg_ms": t_kf, "bound": "latency",
+               "why": "one wave per stream, sequential predict/update chain", "cus_occupied": min((S + 3) // 4, N_CUS),
+               "bytes_per_launch": KF_BYTES * F, "achieved": hbm(KF_BYTES * F, t_kf), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(hbm(KF_BYTES * F, t_kf) / HBM_PEAK_GBS, 5)})
+    ks.append({"kernel": "simdet_kernel", "stage": "detect", "branch": "side", "avg_ms": t_det, "bound": "latency",
+               "bytes_per_launch": SIMDET_BYTES * F, "achieved": hbm(SIMDET_BYTES * F, t_det), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(hbm(SIMDET_BYTES * F, t_det) / HBM_PEAK_GBS, 5)})
+    side, main = t_det + t_trk, t_kf + t_pl
+    dom = max(ks, key=lambda k: k["avg_ms"])
+    roof = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch") if k in dom}
+    roof["avg_launch_ms"] = round(dom["avg_ms"], 5)
+    roof["traffic"] = dom.get("traffic")
+    if dom["bound"] == "latency":
+        roof["cus_occupied"] = dom.get("cus_occupied")
+        roof["note"] = ("dominant kernel is a per-stream sequential chain on %d of %d CUs; its HBM fraction is reported for "
+                        "completeness, the HBM-bound kernel of this step is the planner (see kernels)" % (dom.get("cus_occupied", 0), N_CUS))
+    step_bytes = (TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb
+    out = {"metric": METRIC, "value": round(F * steps * world / el, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 5), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window per step, 1280x720, simulated detection + IoU "
+                                  "tracker + 6-state KF + 21-candidate planner%s" % (name, S, W, ", one hipGraph replay per step" if graph else ""),
+                      "streams_per_gpu": S, "window": W, "graph": bool(graph), "taggers": bool(a.taggers),
+                      "allgather_track_tables": (a.gather if xchg is not None else False),
+                      "parallelism": "stream-sharded x%d" % world},
+           "roofline": roof, "kernels": finish_kernel_list(ks),
+           "step": {"critical_branch": "side (detect+track)" if side > main else "main (kf+plan)",
+                    "side_branch_ms": round(side, 5), "main_branch_ms": round(main, 5),
+                    "algorithmic_bytes": step_bytes,
+                    "hbm_frac_whole_step": round(step_bytes / (el / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+           "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
+    if xchg is not None:
+        out["config"]["allgather_bytes_per_rank_per_step"] = xchg.bytes_per_step
+    if W == 1:
+        out["us_per_time_step"] = round(el / steps * 1e6, 3)
+    del loop, xchg
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 3: YOLO-mode detector + lane detector on device-generated frames
+# ---------------------------------------------------------------------------------------------------------------
+def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     import torch
     import torch.distributed as dist
     from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
     from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import PerceptionLoop
-    S = a.streams or 64
     loop = PerceptionLoop(n_streams=S, device=local)
     L = nat.lib()
-    evs = [[C.c_void_p(), C.c_void_p()] for _ in range(a.steps)]
-    for e in evs:
-        nat.check(L.av_event_create(C.byref(e[0])))
-        nat.check(L.av_event_create(C.byref(e[1])))
-    for _ in range(a.warmup):
-        loop.step()
+    s, side = loop._s, loop.ctx.side_stream
+
+    def one_step():
+        # PerceptionLoop.step_deferred(): the lane chain runs beside the detector on the side stream (both only read
+        # the frames), its Hough + fit half one step late so that it meets the detector's LDS-free first kernels
+        loop.enqueue_generate(stream0=rank * S)
+        nat.check(L.av_fork(loop.ctx.handle, s))
+        if not a.no_defer:
+            if loop._lanes_pending:
+                loop.enqueue_lanes(side, stages=16)
+            loop.enqueue_lanes(side, stages=2)
+            loop._lanes_pending = True
+        else:
+            loop.enqueue_lanes(side)
+        loop.enqueue_detect()
+        nat.check(L.av_join(loop.ctx.handle, s))
+
+    for _ in range(warmup):
+        one_step()
     loop.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        # PerceptionLoop.step_deferred() with events around the detector: the lane chain runs beside it on the side
-        # stream (both only read the frames), its Hough + fit half one step late so that it meets the detector's
-        # LDS-free first kernels; the last frame's half is flushed inside the timed region
-        loop.enqueue_generate(stream0=rank * S)
-        nat.check(L.av_fork(loop.ctx.handle, loop._s))
-        if not a.no_defer:
-            if loop._lanes_pending:
-                loop.enqueue_lanes(loop.ctx.side_stream, stages=16)
-            loop.enqueue_lanes(loop.ctx.side_stream, stages=2)
-            loop._lanes_pending = True
-        else:
-            loop.enqueue_lanes(loop.ctx.side_stream)
-        nat.check(L.av_event_record(evs[k][0], loop._s))
-        loop.enqueue_detect()
-        nat.check(L.av_event_record(evs[k][1], loop._s))
-        nat.check(L.av_join(loop.ctx.handle, loop._s))
-    loop.flush_lanes()
+    for _ in range(steps):
+        one_step()
+    loop.flush_lanes()            # the last frame's Hough half is flushed inside the timed region
     loop.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    ms = C.c_float()
-    tot = 0.0
-    for e in evs:
-        nat.check(L.av_event_elapsed_ms(e[0], e[1], C.byref(ms)))
-        tot += ms.value
-    det_ms = tot / a.steps
-    tfl = loop.flops_per_frame * S / (det_ms * 1e-3) / 1e12
-    if rank == 0:
-        out = {"metric": "end-to-end frames/sec (1280x720 synthetic)", "value": round(S * a.steps * world / el, 1),
-               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (generated on device)",
-               "config": {"workload": "config3: %d camera streams/GPU, 1280x720, YOLO-mode detector (random-init YOLOv8n "
-                                      "topology, letterbox 384x640) + Canny/Hough lane detector" % S,
-                          "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
-               "roofline": {"bound": "mfma", "kernel": "conv_lds_kernel / conv_mfma_kernel (63 launches per forward; timed with preprocess, decode and NMS, beside the lane chain)",
-                            "achieved": round(tfl, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                            "flops_per_launch": int(loop.flops_per_frame * S), "avg_launch_ms": round(det_ms, 4)}}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    el, per_rank_ms = max_over_ranks(el, world)
+
+    sync = loop.synchronize
+    t_gen = time_stage(L, nat, s, loop.enqueue_generate, stage_reps, sync)
+    t_yolo = time_stage(L, nat, s, loop.enqueue_detect, stage_reps, sync)
+    t_pix = time_stage(L, nat, s, lambda: loop.enqueue_lanes(stages=2), stage_reps, sync)
+    t_hough = time_stage(L, nat, s, lambda: loop.enqueue_lanes(stages=16), stage_reps, sync)
+    px = S * loop.h * loop.w
+    fl = loop.flops_per_frame * S
+    tf = fl / (t_yolo * 1e-3) / 1e12
+    pix_bytes = loop.lane_pixel_bytes_per_px * px
+    ks = [
+        {"kernel": "yolo forward: preprocess + 63 conv launches (conv_lds_kernel / conv_mfma_kernel / stem) + sppf + "
+                   "upsample + decode + sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
+         "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
+        {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",
+         "avg_ms": t_pix, "bound": "hbm", "bytes_per_launch": pix_bytes,
+         "achieved": round(pix_bytes / (t_pix * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(pix_bytes / (t_pix * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         "traffic": pmc_traffic("lane_pmc.json", "pixel_stage_hbm_bytes_per_px", px)},
+        {"kernel": "lane Hough + fit: hough_prep + houghp_shard (+ houghp_fast / houghp_kernel fallbacks) + lane_fit",
+         "stage": "lane (Hough)", "branch": "side", "avg_ms": t_hough, "bound": "latency",
+         "why": "sequential probabilistic Hough per frame (cv::RNG order), 4 single-wave workgroups per frame",
+         "cus_occupied": min(4 * S, N_CUS), "bytes_per_launch": px, "achieved": round(px / (t_hough * 1e-3) / 1e9, 1),
+         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(px / (t_hough * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        {"kernel": "synth_rows_kernel", "stage": "generate", "branch": "main", "avg_ms": t_gen, "bound": "hbm",
+         "bytes_per_launch": 3 * px, "achieved": round(3 * px / (t_gen * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(3 * px / (t_gen * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    ]
+    lane_ms = t_pix + t_hough
+    lane_total = LANE_BYTES_PER_PX * px
+    dom = max(ks, key=lambda k: k["avg_ms"])
+    roof = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+            "unit": dom["unit"], "frac": dom["frac"], "traffic": dom.get("traffic"),
+            "avg_launch_ms": round(dom["avg_ms"], 5)}
+    if "flops_per_launch" in dom:
+        roof["flops_per_launch"] = dom["flops_per_launch"]
+        roof["mfma_busy_pmc_percent"] = pmc_value("yolo_mfma_pmc.json", "overall_mfma_busy_percent")
+    out = {"metric": METRIC, "value": round(S * steps * world / el, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": loop.yolo.precision, "data": "synthetic (generated on device)",
+           "config": {"workload": "config3: %d camera streams/GPU, one 1280x720 frame of each per step, YOLO-mode detector "
+                                  "(random-init YOLOv8n topology, letterbox 384x640) + Canny/Hough lane detector" % S,
+                      "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
+           "roofline": roof, "kernels": finish_kernel_list(ks),
+           "lane_chain": {"avg_ms": round(lane_ms, 5), "bytes_per_launch": lane_total,
+                          "achieved": round(lane_total / (lane_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(lane_total / (lane_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "SURVEY 8d: 7*W*H algorithmic bytes per frame over pixel stages + Hough + fit"},
+           "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
+    del loop
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,6 +458,16 @@ def main():
         print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus,
               file=sys.stderr)
         sys.exit(2)
+
+    # CPU legs first: nothing has touched the GPU yet, so child processes are safe to start
+    cpu_hot = cpu_pix = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu_hot = cpu_hot_loop(a.cpu_seconds)
+        if not a.no_also or a.workload == "config3":
+            cpu_pix = cpu_pixel_path(a.cpu_seconds)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         print("bench.py needs a HIP device", file=sys.stderr)
         sys.exit(2)
@@ -151,127 +476,41 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    def with_cpu(line, cpu):
+        if cpu is not None:
+            line["cpu_baseline"] = dict(cpu)
+            line["cpu_baseline"]["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+            if "nproc" in cpu:
+                line["cpu_baseline"]["gpu_over_cpu_nproc"] = round(line["value"] / cpu["nproc"]["value"], 1)
+        return line
+
+    def hot(name, S, W, graph, steps, warmup):
+        return run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup)
+
     if a.workload == "config3":
-        return bench_config3(a, world, rank, local)
-    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
-    from multimodal_autonomous_driving_perception_and_planning_amd.distributed import TrackTableExchange
-    from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion
+        head = with_cpu(run_config3(a, world, rank, local, a.streams or 64, a.steps, a.warmup), cpu_pix)
+    elif a.workload == "config2":
+        g = bool(a.graph) if a.graph is not None else False
+        head = with_cpu(hot("config2", a.streams or 1, a.window or 131072, g, a.steps, a.warmup), cpu_hot)
+    else:
+        g = True if a.graph is None else bool(a.graph)
+        head = with_cpu(hot("config4", a.streams or 64, a.window or 256, g, a.steps, a.warmup), cpu_hot)
 
-    S = a.streams or (1 if a.workload == "config2" else 64)
-    W = a.window or (131072 if a.workload == "config2" else 256)
-    loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True)
-    L = nat.lib()
-    g0 = rank * S                                      # global stream ids of this rank
-    loop.reset(frame_offsets=[(g0 + s) * 17 for s in range(S)])   # offset s*17
-    # synthetic ego measurements: one seeded sequence per stream, re-used every window (input data only)
-    z = np.stack([np.asarray(generate_ego_motion(W, seed=g0 + s), np.float64) for s in range(S)])
-    loop.load_measurements(z)
-    xchg = None
-    if world > 1 and not a.no_allgather:
-        xchg = TrackTableExchange(loop, world, rank)
-
-    evs = [[C.c_void_p(), C.c_void_p()] for _ in range(a.steps)]
-    for e in evs:
-        nat.check(L.av_event_create(C.byref(e[0])))
-        nat.check(L.av_event_create(C.byref(e[1])))
-
-    def one_step(k, timed):
-        if a.graph:
-            loop.step(graph=True)
-        else:
-            # side stream: detect -> track (stream order alone keeps steps apart there); main: kf -> plan; join.
-            # No fork is needed outside graph capture: nothing on the side stream depends on the main one.
-            h, s = loop.ctx.handle, loop._s
-            loop.enqueue_detect(loop.ctx.side_stream)
-            loop.enqueue_track(loop.ctx.side_stream)
-            loop.enqueue_kf()
-            if timed:
-                nat.check(L.av_event_record(evs[k][0], s))
-            loop.enqueue_plan()
-            if timed:
-                nat.check(L.av_event_record(evs[k][1], s))
-            if a.taggers:
-                loop.enqueue_maneuver()                   # consumes the Kalman output (main stream)
-            # the two chains share no buffer, so they only have to meet when somebody reads across them: per step
-            # for the track-table exchange or the interaction tagger, otherwise once before the final synchronisation
-            if xchg is not None or a.taggers:
-                nat.check(L.av_join(h, s))
-            if a.taggers:
-                loop.enqueue_interactions()               # consumes the tracker's tables and the Kalman output
-        if xchg is not None:
-            xchg.exchange()
-
-    def drain():
-        if not a.graph:
-            nat.check(L.av_join(loop.ctx.handle, loop._s))       # main stream waits for the side stream's tail
-        loop.synchronize()
-
-    for k in range(a.warmup):
-        one_step(k, False)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_step(k, True)
-    drain()
-    if xchg is not None:
-        xchg.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # dominant-by-bytes kernel: the planner (51.7 KB written per frame vs 4.8 KB tracker, 0.8 KB KF)
-    if a.graph:
-        for k in range(a.steps):      # graph nodes cannot be bracketed; time the same launches directly
-            nat.check(L.av_event_record(evs[k][0], loop._s))
-            loop.enqueue_plan()
-            nat.check(L.av_event_record(evs[k][1], loop._s))
-        loop.synchronize()
-    ms = C.c_float()
-    tot = 0.0
-    for e in evs:
-        nat.check(L.av_event_elapsed_ms(e[0], e[1], C.byref(ms)))
-        tot += ms.value
-    plan_ms = tot / a.steps
-    plan_bytes = loop.planner_bytes_per_state() * S * W
-    ach = plan_bytes / (plan_ms * 1e-3) / 1e9
+    if world == 1 and not a.no_also and a.workload == "config4":
+        also = {}
+        also["config4_w1"] = with_cpu(hot("config4 (window 1)", a.streams or 64, 1, True, 2000, 200), cpu_hot)
+        also["config3"] = with_cpu(run_config3(a, world, rank, local, 64, 20, 5), cpu_pix)
+        also["config2"] = with_cpu(hot("config2", 1, 32768, False, 4, 1), cpu_hot)
+        also["config2_w1"] = with_cpu(hot("config2 (window 1)", 1, 1, True, 2000, 200), cpu_hot)
+        also["config4_256streams"] = with_cpu(hot("config4 scaled to 256 streams (not a BASELINE config: shows the "
+                                                  "HBM-bound regime once every CU has a tracker stream)", 256, 256, True, 10, 3), cpu_hot)
+        for v in also.values():          # the headline's fixed keys stay on the headline only
+            for k in ("metric", "higher_is_better", "scaling", "vs_baseline", "n_gpus", "ranks_seen", "per_rank_ms"):
+                v.pop(k, None)
+        head["also"] = also
 
     if rank == 0:
-        frames = S * W * a.steps * world
-        # HBM bytes per launch from the PMC counters (WRITE_SIZE + corrected FETCH_SIZE), collected with
-        # rocprofv3 in separate passes and committed under profiles/ (per start state, scaled to this launch)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "planner_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = int(json.load(open(pmc))["hbm_bytes_per_state"] * S * W)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "end-to-end frames/sec (1280x720 synthetic)", "value": round(frames / el, 1),
-            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window, 1280x720, simulated detection + IoU "
-                                   "tracker + 6-state KF + 21-candidate planner" % (a.workload, S, W),
-                       "streams_per_gpu": S, "window": W, "graph": bool(a.graph), "taggers": bool(a.taggers),
-                       "allgather_track_tables": bool(xchg is not None), "parallelism": "stream-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "planner_wave_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": plan_bytes, "avg_launch_ms": round(plan_ms, 5)},
-        }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-            out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(head), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -135,6 +135,35 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
                       const int32_t* det_cls, const double* det_conf, int tcap, void* state,
                       av_track_row* snap, int32_t* snap_n, int32_t* det2trk);
 
+/* Wire format of a track table for the all-gather of per-frame track tables across ranks (BASELINE config 5,
+ * SURVEY.md section 8e; the reference has no multi-process code, F9).  What travels is what a consumer of
+ * MultiObjectTracker.update()'s return value reads (multi_object_tracker.py:236-241): a 16-byte header and tcap
+ * 32-byte rows, rows >= n_rows zero-filled.  Lossy against av_track_row only in `conf` (float32), `misses`
+ * (saturates at 65535) and coordinates (int16: frames up to 32767 px); slot / hist_len stay local. */
+#define AV_WIRE_HDR_BYTES 16
+#define AV_WIRE_ROW_BYTES 32
+typedef struct {
+    int32_t n_rows, stream, frame, reserved;   /* global stream id, frame index within the run */
+} av_wire_hdr;
+typedef struct {
+    int32_t id;
+    int16_t x1, y1, x2, y2;
+    int32_t age, hits;
+    uint16_t misses;
+    uint8_t cls, flags;          /* flags bit0: confirmed */
+    float conf;
+    int16_t vx2, vy2;            /* 2 x the last centre velocity (half-integers, so exact) */
+} av_wire_row;
+size_t av_wire_table_bytes(int tcap);          /* AV_WIRE_HDR_BYTES + tcap * AV_WIRE_ROW_BYTES */
+/* Packs the tables of frames [frame_lo, frame_lo + n_sel) of every stream of a window into
+ *   wire [n_streams][n_sel][av_wire_table_bytes(tcap)]
+ * (n_sel = 1, frame_lo = n_frames - 1: the end-of-window table; n_sel = n_frames: every frame's table).
+ * stream0 / frame0 are added to the header's stream / frame fields (this rank's first global stream id and the
+ * window's first frame index).  The gather itself is torch.distributed's all_gather_into_tensor on `wire`
+ * (RCCL over xGMI; distributed.TrackTableExchange). */
+int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
+                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, void* wire);
+
 /* ---- E1-E3: vehicle state estimator ------------------------------------------------------------
  * Replaces VehicleStateEstimator.predict/update/step/_extract_state
  * (src/state_estimation/vehicle_state.py:68-198) incl. filterpy's predict/update equations. */

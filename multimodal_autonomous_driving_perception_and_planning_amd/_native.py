@@ -86,6 +86,8 @@ _SIGS = [
     ("av_tracker_reset", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     ("av_tracker_update", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_int, vp, vp, vp, vp]),
+    ("av_wire_table_bytes", C.c_size_t, [C.c_int]),
+    ("av_pack_tracks", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     ("av_kf_reset", C.c_int, [vp, vp, C.c_int, vp]),
     ("av_kf_step", C.c_int, [vp, vp, C.POINTER(KfCfg), C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     ("av_planner_configure", C.c_int, [vp, C.POINTER(PlannerCfg)]),

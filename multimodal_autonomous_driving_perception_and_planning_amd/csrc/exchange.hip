@@ -1,0 +1,73 @@
+// Wire format of the per-frame track tables that ranks all-gather (BASELINE config 5).
+//
+// The reference has no counterpart (no multi-process code at all); the consumer is what reads
+// MultiObjectTracker.update()'s return value (src/tracking/multi_object_tracker.py:236-241), e.g. the interaction
+// tagger.  A table travels as a 16-byte header + tcap x 32-byte rows ("Tcap=64 rows x 32 B"), half of
+// the 64-byte rows the tracker keeps in HBM: HBM-bound byte shuffling, one thread per row, coalesced 64-B reads
+// and 32-B writes.
+#include "common.h"
+
+namespace {
+
+// one thread per (table, row); tables are [n_streams][n_sel] selected frames of snap[n_streams][n_frames][tcap]
+__global__ void __launch_bounds__(256) pack_tracks_kernel(int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
+                                                          int stream0, int frame0, const av_track_row* __restrict__ snap,
+                                                          const int32_t* __restrict__ snap_n, uint8_t* __restrict__ wire) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)n_streams * n_sel * tcap;
+    if (i >= total) return;
+    const int r = (int)(i % tcap);
+    const long long t = i / tcap;                       // table index = s * n_sel + k
+    const int s = (int)(t / n_sel), k = (int)(t - (long long)s * n_sel);
+    const int f = frame_lo + k;
+    const int n = snap_n[(size_t)s * n_frames + f];
+    const size_t tb = AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES;
+    uint8_t* dst = wire + (size_t)t * tb;
+    if (r == 0) {
+        av_wire_hdr h;
+        h.n_rows = n < tcap ? n : tcap;
+        h.stream = stream0 + s;
+        h.frame = frame0 + f;
+        h.reserved = 0;
+        *reinterpret_cast<av_wire_hdr*>(dst) = h;
+    }
+    av_wire_row o;
+    if (r < n) {
+        const av_track_row in = snap[((size_t)s * n_frames + f) * tcap + r];
+        o.id = in.id;
+        o.x1 = (int16_t)in.x1, o.y1 = (int16_t)in.y1, o.x2 = (int16_t)in.x2, o.y2 = (int16_t)in.y2;
+        o.age = in.age, o.hits = in.hits;
+        o.misses = (uint16_t)(in.misses > 65535 ? 65535 : in.misses);
+        o.cls = (uint8_t)in.cls, o.flags = (uint8_t)in.flags;
+        o.conf = (float)in.conf;
+        // centre velocities are differences of half-integers: 2*v is an exact integer
+        o.vx2 = (int16_t)(in.vx * 2.0f), o.vy2 = (int16_t)(in.vy * 2.0f);
+    } else {
+        o.id = 0, o.x1 = o.y1 = o.x2 = o.y2 = 0, o.age = o.hits = 0, o.misses = 0, o.cls = 0, o.flags = 0, o.conf = 0.0f;
+        o.vx2 = o.vy2 = 0;
+    }
+    reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t av_wire_table_bytes(int tcap) { return AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES; }
+
+int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
+                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, void* wire) {
+    AV_REQUIRE(ctx && snap && snap_n && wire, AV_EINVAL, "av_pack_tracks: null argument");
+    AV_REQUIRE(n_streams > 0 && n_frames > 0 && tcap > 0 && tcap <= 1024, AV_EINVAL, "av_pack_tracks: bad dimensions");
+    AV_REQUIRE(frame_lo >= 0 && n_sel > 0 && frame_lo + n_sel <= n_frames, AV_EINVAL,
+               "av_pack_tracks: frames [%d, %d) outside the window of %d", frame_lo, frame_lo + n_sel, n_frames);
+    static_assert(sizeof(av_wire_row) == AV_WIRE_ROW_BYTES && sizeof(av_wire_hdr) == AV_WIRE_HDR_BYTES, "wire layout");
+    const long long total = (long long)n_streams * n_sel * tcap;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_tracks_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_streams, n_frames, tcap,
+                       frame_lo, n_sel, stream0, frame0, snap, snap_n, (uint8_t*)wire);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+}  // extern "C"

@@ -7,14 +7,26 @@ all-gather of the track tables (a fleet-wide view for downstream consumers such 
 InteractionDetector); the reference itself has no counterpart.
 
 One process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI) on the GPU box, "gloo"
-in the CPU tests.  The gather runs on its own stream, double-buffered, so window k's exchange
-overlaps window k+1's kernels.
+in the CPU tests.  Tables travel in the 32-byte-per-row wire format of include/avhot.h
+(av_wire_hdr / av_wire_row), packed on the device by av_pack_tracks; the gather runs on its own
+stream, double-buffered, so window k's exchange overlaps window k+1's kernels.
+
+Two modes (bytes per rank per step at S = 64 streams, tcap = 64, 2064 B per table):
+  window-end  one table per stream per step: the table after the window's last frame        132 KB
+  per-frame   every frame's table of the window (BASELINE config 5's wording); with W = 256  33.8 MB,
+              with W = 1 (one step per time-step) the two modes coincide                     132 KB
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import _native as nat
+
+WIRE_HDR_BYTES, WIRE_ROW_BYTES = 16, 32
+WIRE_HDR_FIELDS = [("n_rows", "<i4"), ("stream", "<i4"), ("frame", "<i4"), ("reserved", "<i4")]
+WIRE_ROW_FIELDS = [("id", "<i4"), ("x1", "<i2"), ("y1", "<i2"), ("x2", "<i2"), ("y2", "<i2"), ("age", "<i4"),
+                   ("hits", "<i4"), ("misses", "<u2"), ("cls", "u1"), ("flags", "u1"), ("conf", "<f4"),
+                   ("vx2", "<i2"), ("vy2", "<i2")]
 
 
 def shard_streams(n_streams_total, world, rank):
@@ -24,9 +36,56 @@ def shard_streams(n_streams_total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-WIRE_ROW_BYTES = nat.TRACK_ROW_BYTES
+def wire_table_bytes(tcap):
+    return WIRE_HDR_BYTES + tcap * WIRE_ROW_BYTES
 
 
+def pack_wire(snap_u8, snap_n, frame_lo, n_sel, stream0=0, frame0=0):
+    """Host/torch statement of av_pack_tracks (the HIP kernel is checked against it bit for bit; the CPU tests and
+    CPU-tensor exchanges use it directly).  snap_u8 [S, W, tcap, 64] uint8, snap_n [S, W] int32 ->
+    [S, n_sel, wire_table_bytes(tcap)] uint8."""
+    S, W, tcap, _ = snap_u8.shape
+    sel = snap_u8[:, frame_lo:frame_lo + n_sel].contiguous()
+    n = snap_n[:, frame_lo:frame_lo + n_sel].to(torch.int32).clamp(max=tcap).contiguous()
+    w = sel.view(torch.int32).reshape(S, n_sel, tcap, 16)
+    live = (torch.arange(tcap, device=sel.device).view(1, 1, tcap) < n.unsqueeze(-1))
+    conf = sel.view(torch.float64).reshape(S, n_sel, tcap, 8)[..., 6].to(torch.float32)
+    vel = sel.view(torch.float32).reshape(S, n_sel, tcap, 16)[..., 14:16]
+    out = torch.zeros(S, n_sel, tcap, WIRE_ROW_BYTES, dtype=torch.uint8, device=sel.device)
+
+    def put(lo, t):
+        t = torch.where(live.view(S, n_sel, tcap, *([1] * (t.dim() - 3))), t, torch.zeros_like(t)).contiguous()
+        b = t.view(torch.uint8).reshape(S, n_sel, tcap, -1)
+        out[..., lo:lo + b.shape[-1]] = b
+    put(0, w[..., 0:1])                                             # id
+    put(4, w[..., 1:5].to(torch.int16))                             # box
+    put(12, w[..., 6:8])                                            # age, hits
+    put(20, w[..., 8:9].clamp(max=65535).to(torch.int32).to(torch.int16))   # misses (two's complement of u16)
+    put(22, w[..., 5:6].to(torch.uint8))                            # cls
+    put(23, w[..., 11:12].to(torch.uint8))                          # flags
+    put(24, conf.unsqueeze(-1))
+    put(28, (vel * 2.0).to(torch.int16))
+    hdr = torch.zeros(S, n_sel, 4, dtype=torch.int32, device=sel.device)
+    hdr[..., 0] = n
+    hdr[..., 1] = stream0 + torch.arange(S, device=sel.device, dtype=torch.int32).view(S, 1)
+    hdr[..., 2] = frame0 + frame_lo + torch.arange(n_sel, device=sel.device, dtype=torch.int32).view(1, n_sel)
+    msg = torch.empty(S, n_sel, wire_table_bytes(tcap), dtype=torch.uint8, device=sel.device)
+    msg[..., :WIRE_HDR_BYTES] = hdr.view(torch.uint8).reshape(S, n_sel, WIRE_HDR_BYTES)
+    msg[..., WIRE_HDR_BYTES:] = out.reshape(S, n_sel, tcap * WIRE_ROW_BYTES)
+    return msg
+
+
+def unpack_wire(msg, tcap):
+    """Gathered [..., wire_table_bytes(tcap)] uint8 (tensor or array) -> (hdr structured [...], rows structured [..., tcap])."""
+    m = msg.cpu().numpy() if isinstance(msg, torch.Tensor) else np.asarray(msg)
+    lead = m.shape[:-1]
+    m = np.ascontiguousarray(m.reshape(-1, wire_table_bytes(tcap)))
+    hdr = np.ascontiguousarray(m[:, :WIRE_HDR_BYTES]).view(np.dtype(WIRE_HDR_FIELDS)).reshape(lead)
+    rows = np.ascontiguousarray(m[:, WIRE_HDR_BYTES:]).view(np.dtype(WIRE_ROW_FIELDS)).reshape(lead + (tcap,))
+    return hdr, rows
+
+
+# ---- the 64-byte-row message of round 1 (kept: the class API below no longer uses it) ------------------
 def pack_tables(rows_u8, counts):
     """[S, tcap, 64] uint8 rows + [S] int32 counts -> one [S, tcap*64 + 64] uint8 message."""
     S, tcap, rb = rows_u8.shape
@@ -45,37 +104,53 @@ def unpack_tables(msg, tcap):
 
 
 def all_gather_tables(msg, world, group=None):
-    """Blocking all-gather of a packed message; returns [world*S, bytes]."""
-    out = torch.empty(world * msg.shape[0], msg.shape[1], dtype=msg.dtype, device=msg.device)
+    """Blocking all-gather of a packed message; returns [world*S, ...]."""
+    out = torch.empty((world * msg.shape[0],) + tuple(msg.shape[1:]), dtype=msg.dtype, device=msg.device)
     dist.all_gather_into_tensor(out, msg.contiguous(), group=group)
     return out
 
 
 class TrackTableExchange:
-    """Per window: gather every rank's end-of-window track tables (one per local stream)."""
+    """Per step: pack this rank's track tables into the wire format and all-gather them over all ranks.
 
-    def __init__(self, loop, world, rank, group=None):
-        self.loop, self.world, self.rank, self.group = loop, world, rank, group
-        S, tcap = loop.S, loop.tcap
-        nbytes = tcap * WIRE_ROW_BYTES + 64
-        dev = loop.dev
-        self.send = [torch.zeros(S, nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.recv = [torch.zeros(world * S, nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.comm = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event() for _ in range(2)]
+    `loop` provides S, W, tcap, dev, snap [S,W,tcap,64] u8, snap_n [S,W] i32 and -- on a GPU -- `stream`
+    (a torch.cuda.Stream the step was enqueued on) and `ctx` (av_ctx).  With CPU tensors (gloo tests) the same
+    code path runs synchronously with the torch statement of the pack kernel.
+    per_frame=False: the end-of-window table of every stream; True: all W tables of the window."""
+
+    def __init__(self, loop, world, rank, group=None, per_frame=False):
+        self.loop, self.world, self.rank, self.group, self.per_frame = loop, world, rank, group, per_frame
+        S, tcap, dev = loop.S, loop.tcap, loop.dev
+        self.n_sel = loop.W if per_frame else 1
+        self.frame_lo = 0 if per_frame else loop.W - 1
+        tb = wire_table_bytes(tcap)
+        self.bytes_per_step = S * self.n_sel * tb
+        self.gpu = torch.device(dev).type == "cuda"
+        self.send = [torch.zeros(S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.recv = [torch.zeros(world * S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
+        if self.gpu:
+            self.comm = torch.cuda.Stream(device=dev)
+            self.ready = [torch.cuda.Event() for _ in range(2)]
         self.done = [None, None]
-        self.k = 0
+        self.k = 0                      # steps exchanged so far; step k uses buffer k & 1
 
     def exchange(self):
+        """Enqueue pack + all-gather of the step just enqueued on loop.stream; returns the receive buffer
+        ([world*S, n_sel, table bytes], complete once synchronize() / latest() returns)."""
         b = self.k & 1
         loop = self.loop
-        if self.done[b] is not None:           # buffer b is still being sent from two windows ago
+        frame0 = self.k * loop.W
+        if not self.gpu:
+            self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0))
+            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
+            self.k += 1
+            return self.recv[b]
+        if self.done[b] is not None:           # buffer b is still being sent from two steps ago
             loop.stream.wait_event(self.done[b])
-        tb = loop.tcap * WIRE_ROW_BYTES
-        with torch.cuda.stream(loop.stream):
-            self.send[b][:, :tb] = loop.snap[:, loop.W - 1].reshape(loop.S, tb)
-            self.send[b][:, tb:tb + 4] = loop.snap_n[:, loop.W - 1].contiguous().view(torch.uint8).reshape(loop.S, 4)
-            self.ready[b].record(loop.stream)
+        nat.check(nat.lib().av_pack_tracks(loop.ctx.handle, nat.stream_handle(loop.stream), loop.S, loop.W, loop.tcap,
+                                           self.frame_lo, self.n_sel, self.rank * loop.S, frame0, nat.ptr(loop.snap),
+                                           nat.ptr(loop.snap_n), nat.ptr(self.send[b])))
+        self.ready[b].record(loop.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])
             dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
@@ -86,10 +161,11 @@ class TrackTableExchange:
         return self.recv[b]
 
     def latest(self):
-        """Host view (rows [world*S, tcap], counts [world*S]) of the most recent completed gather."""
+        """Host view (hdr [world*S, n_sel], rows [world*S, n_sel, tcap]) of the most recent gather."""
         self.synchronize()
         b = (self.k - 1) & 1
-        return unpack_tables(self.recv[b], self.loop.tcap)
+        return unpack_wire(self.recv[b], self.loop.tcap)
 
     def synchronize(self):
-        self.comm.synchronize()
+        if self.gpu:
+            self.comm.synchronize()

@@ -85,6 +85,7 @@ class YoloV8n:
             raise ValueError("parameter vector has %d floats, the YOLOv8n graph needs %d" % (self.params.size, n))
         self.names = dict(enumerate(COCO_NAMES))
         self.batch = batch
+        self.precision = "bf16"          # MFMA operand type of the convolutions (float32 accumulation)
         self._h = None
         self._shape = None
 

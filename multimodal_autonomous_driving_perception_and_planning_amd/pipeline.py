@@ -256,6 +256,11 @@ class PerceptionLoop:
         for cin, cout, k, s, _ in conv_specs():
             sizes.append((cin, cout, k, s))
         self.flops_per_frame = _yolo_flops(net_h, net_w)
+        # algorithmic HBM bytes per pixel of the lane pixel stages (bench.py): read BGR 3, write + read the blurred image 2,
+        # write the edge map 1; the Hough stage's read of the edge map is the 7th byte of SURVEY 8d's 7*W*H
+        self.lane_pixel_bytes_per_px = 6
+        self.lane_pixel_kernels = ("gray_blur_hist_stream + thresholds + sobel_nms_stream + ccl_tile + ccl_border + "
+                                   "finalize_fast + compact")
         self.frame_idx = 0
         self._lanes_pending = False
         self.stream.synchronize()

@@ -211,9 +211,10 @@ def test_full_size_properties(torch_gpu):
 
 
 def test_track_table_exchange_single_rank_nccl(torch_gpu):
-    """Exercises the RCCL path (one rank): window k's gather overlaps window k+1 and returns the right tables."""
+    """Exercises the RCCL path (one rank), both gather modes: step k's gather overlaps step k+1 and returns the right
+    tables; the device pack kernel (av_pack_tracks) equals its torch statement bit for bit."""
     import torch.distributed as dist
-    from multimodal_autonomous_driving_perception_and_planning_amd.distributed import TrackTableExchange
+    from multimodal_autonomous_driving_perception_and_planning_amd import distributed as D
     from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
     from oracle.harness_ref import ego_motion
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -221,17 +222,32 @@ def test_track_table_exchange_single_rank_nccl(torch_gpu):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch_gpu.device("cuda", 0))
     try:
         S, W = 4, 32
-        loop = HotLoop(n_streams=S, window=W, keep_waypoints=False)
-        loop.load_measurements(np.stack([ego_motion(W, seed=s) for s in range(S)]))
-        x = TrackTableExchange(loop, 1, 0)
-        for _ in range(3):
-            loop.step()
-            x.exchange()
-        rows, counts = x.latest()
-        want_rows, want_n = loop.snapshots()
-        assert np.array_equal(counts, want_n[:, -1])
-        for s in range(S):
-            assert np.array_equal(rows["id"][s, :counts[s]], want_rows[s, -1]["id"][:counts[s]])
+        for per_frame in (False, True):
+            loop = HotLoop(n_streams=S, window=W, keep_waypoints=False)
+            loop.load_measurements(np.stack([ego_motion(W, seed=s) for s in range(S)]))
+            x = D.TrackTableExchange(loop, 1, 0, per_frame=per_frame)
+            for _ in range(3):
+                loop.step()
+                x.exchange()
+            hdr, rows = x.latest()
+            want_rows, want_n = loop.snapshots()
+            frames = range(W) if per_frame else [W - 1]
+            assert hdr.shape == (S, len(frames))
+            for s in range(S):
+                for j, f in enumerate(frames):
+                    n = want_n[s, f]
+                    assert hdr["n_rows"][s, j] == n and hdr["stream"][s, j] == s and hdr["frame"][s, j] == 2 * W + f
+                    w = want_rows[s, f][:n]
+                    g = rows[s, j]
+                    for k in ("id", "x1", "y1", "x2", "y2", "age", "hits", "misses", "cls", "flags"):
+                        assert np.array_equal(g[k][:n], w[k]), k
+                    assert np.array_equal(g["conf"][:n], w["conf"].astype(np.float32))
+                    assert np.array_equal(g["vx2"][:n], (2 * w["vx"]).astype(np.int16))
+                    assert np.array_equal(g["vy2"][:n], (2 * w["vy"]).astype(np.int16))
+                    assert not g[n:].view(np.uint8).any()
+            # kernel == torch statement on the same device tables (whole messages, bytewise)
+            ref = D.pack_wire(loop.snap, loop.snap_n, x.frame_lo, x.n_sel, 0, 2 * W)
+            assert torch_gpu.equal(ref, x.send[(x.k - 1) & 1])
     finally:
         dist.destroy_process_group()
 
