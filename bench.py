@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF
 N_CUS = 256
+CPU_SHARE = 16                 # host cores that go with one GPU of an 8-GPU node (process / thread pools are sized to it)
 PKG = "multimodal_autonomous_driving_perception_and_planning_amd"
 METRIC = "end-to-end frames/sec (1280x720 synthetic)"
 
@@ -84,7 +85,7 @@ def cpu_hot_loop(seconds):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    P = max(1, min(ncpu, 64))
+    P = max(1, min(ncpu, CPU_SHARE))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD, str(n)], stdout=subprocess.PIPE, env=env) for _ in range(P)]
@@ -113,6 +114,7 @@ def cpu_pixel_path(seconds):
         n += 1
     lane_ms = (time.perf_counter() - t0) / n * 1e3
     net = yolo_ref.build_model(yolo_ref.random_params(0))
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), CPU_SHARE)))
     thr = torch.get_num_threads()
 
     def one(fr):

@@ -4,13 +4,13 @@
 // ultralytics YOLO("yolov8n.pt")(frame) (third party, not vendored; topology restated in
 // oracle/yolo_ref.py, which also defines the parameter order this file consumes).
 //
-// Layout: activations are NHWC bf16 with an explicit channel stride, so a producer can write straight
+// Layout: activations are NHWC half with an explicit channel stride, so a producer can write straight
 // into a channel slice of a concat buffer (every Concat / chunk of the graph is free) and a consumer can
-// read a slice.  Convolution = implicit GEMM on v_mfma_f32_16x16x32_bf16 with the *weights* as the A
+// read a slice.  Convolution = implicit GEMM on v_mfma_f32_16x16x32_f16 with the *weights* as the A
 // operand (rows = output channels) and the gathered input patch as B (columns = output pixels): the
 // accumulator then holds 4 consecutive channels of one pixel per lane, i.e. an 8-byte NHWC store.
 // BatchNorm (eval) is folded into weights/bias on the host; SiLU, the Bottleneck residual and the
-// bf16 conversion are fused into the epilogue.  K = taps*Cin is padded to a multiple of 32; Cin is
+// half conversion are fused into the epilogue.  K = taps*Cin is padded to a multiple of 32; Cin is
 // always a multiple of 8, so one lane's 8-element fragment never straddles a filter tap.
 #include "common.h"
 
@@ -21,33 +21,30 @@
 
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) short;
+// Element type of activations and weights: IEEE half (11 significant bits, float32 accumulation in the MFMA).  ultralytics'
+// own GPU inference mode is half precision; bf16 (8 bits) was measured first and moved boxes by several pixels against the
+// fp32 restatement (tests/test_gpu_yolo.py: end-to-end parity), at the same MFMA rate.
+typedef _Float16 half_t;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-typedef unsigned short bf16_t;
+struct alignas(8) half4 { half_t x, y, z, w; };
 
 constexpr int NC = 80, REG_MAX = 16, MAX_CAND = 8192;
 
-__host__ __device__ inline bf16_t f2bf(float f) {
-    unsigned u;
-#ifdef __HIP_DEVICE_COMPILE__
-    u = __float_as_uint(f);
-#else
-    memcpy(&u, &f, 4);
-#endif
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ inline float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+__host__ __device__ inline half_t f2h(float f) { return (half_t)f; }          // round to nearest even (v_cvt_f16_f32)
+__device__ inline float h2f(half_t b) { return (float)b; }
+__device__ inline half4 make_half4(float a, float b, float c, float d) { return half4{f2h(a), f2h(b), f2h(c), f2h(d)}; }
 
 struct ConvArgs {
-    const bf16_t* in;   int in_cs, in_coff, cin, H, W;        // input NHWC (batch folded into pixels via n)
-    const bf16_t* wgt;  const float* bias; int kpad, kreal, ksz, stride;
-    bf16_t* out;        float* out32; int out_cs, out_coff, cout, Ho, Wo;
-    const bf16_t* res;  int res_cs, res_coff;                 // optional residual (added after the activation)
+    const half_t* in;   int in_cs, in_coff, cin, H, W;        // input NHWC (batch folded into pixels via n)
+    const half_t* wgt;  const float* bias; int kpad, kreal, ksz, stride;
+    half_t* out;        float* out32; int out_cs, out_coff, cout, Ho, Wo;
+    const half_t* res;  int res_cs, res_coff;                 // optional residual (added after the activation)
     int act, npix;                                            // npix = B*Ho*Wo
 };
 
-// SiLU with v_rcp_f32 (1 ulp) instead of an IEEE divide: the result is rounded to bf16 anyway, and the epilogue of
+// SiLU with v_rcp_f32 (1 ulp) instead of an IEEE divide: the result is rounded to half anyway, and the epilogue of
 // these small convolutions is as long as their K loop.
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -75,28 +72,28 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     int k = 8 * h, tap = k / a.cin, ci = k - tap * a.cin;
-    const bf16_t* wrow[MT];
+    const half_t* wrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.wgt + (size_t)(ch_base + mt * 16 + l15) * a.kpad + 8 * h;
     for (int k0 = 0; k0 < a.kpad; k0 += 32) {
         const int ky = a.ksz == 1 ? 0 : tap / 3, kx = a.ksz == 1 ? 0 : tap - ky * 3;
         const bool kv = (k0 + 8 * h) < a.kreal;
-        bf16x8 A[MT], B[NT];
+        half8 A[MT], B[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const bf16x8*>(wrow[mt] + k0);
+        for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const half8*>(wrow[mt] + k0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int iy = iy0[nt] + ky, ix = ix0[nt] + kx;
             const bool ok = kv && pv[nt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *reinterpret_cast<const bf16x8*>(a.in + ((size_t)(nb[nt] + iy) * a.W + ix) * a.in_cs + a.in_coff + ci);
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const half8*>(a.in + ((size_t)(nb[nt] + iy) * a.W + ix) * a.in_cs + a.in_coff + ci);
             B[nt] = v;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
         ci += 32;
         while (ci >= a.cin) ci -= a.cin, ++tap;
     }
@@ -114,13 +111,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
             if (a.res) {
-                const ushort4 rr = *reinterpret_cast<const ushort4*>(a.res + p * a.res_cs + a.res_coff + ch);
-                v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
+                const half4 rr = *reinterpret_cast<const half4*>(a.res + p * a.res_cs + a.res_coff + ch);
+                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
             }
             if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
             else
-                *reinterpret_cast<ushort4*>(a.out + p * a.out_cs + a.out_coff + ch) =
-                    make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+                *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -196,17 +192,17 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     gload(0);
     // bias and residual of this lane's outputs are fetched now: in the epilogue their latency would be exposed
     float4 bsv[MT];
-    ushort4 resv[MT][2];
+    half4 resv[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ch = ch_base + mt * 16 + 4 * h;
         bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            resv[mt][nt] = make_ushort4(0, 0, 0, 0);
+            resv[mt][nt] = make_half4(0.f, 0.f, 0.f, 0.f);
             const int oy = oy0 + 2 * wave + nt, ox = ox0 + l15;
             if (a.res && oy < a.Ho && ox < a.Wo)
-                resv[mt][nt] = *reinterpret_cast<const ushort4*>(a.res + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.res_cs + a.res_coff + ch);
+                resv[mt][nt] = *reinterpret_cast<const half4*>(a.res + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.res_cs + a.res_coff + ch);
         }
     }
     for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
@@ -221,18 +217,18 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
         if (c0 + LT_CK < a.cin) gload(c0 + LT_CK);
         for (int tap = 0; tap < taps; ++tap) {
             const int ky = KS == 1 ? 0 : tap / 3, kx = KS == 1 ? 0 : tap - ky * 3;
-            bf16x8 A[MT], B[2];
+            half8 A[MT], B[2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                A[mt] = *reinterpret_cast<const bf16x8*>(wts + (size_t)(mt * 16 + l15) * wrowb + (tap * LT_CK + 8 * h) * 2);
+                A[mt] = *reinterpret_cast<const half8*>(wts + (size_t)(mt * 16 + l15) * wrowb + (tap * LT_CK + 8 * h) * 2);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                B[nt] = *reinterpret_cast<const bf16x8*>(patch + (size_t)(((2 * wave + nt) * s + ky) * PW + l15 * s + kx) * LT_PIXB + 16 * h);
+                B[nt] = *reinterpret_cast<const half8*>(patch + (size_t)(((2 * wave + nt) * s + ky) * PW + l15 * s + kx) * LT_PIXB + 16 * h);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -249,13 +245,12 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
             if (a.res) {
-                const ushort4 rr = resv[mt][nt];
-                v[0] += bf2f(rr.x), v[1] += bf2f(rr.y), v[2] += bf2f(rr.z), v[3] += bf2f(rr.w);
+                const half4 rr = resv[mt][nt];
+                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
             }
             if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
             else
-                *reinterpret_cast<ushort4*>(a.out + p * a.out_cs + a.out_coff + ch) =
-                    make_ushort4(f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]));
+                *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -266,8 +261,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 // receptive field is two MFMA steps.  Half the bytes of the 8-channel layout on both sides of the kernel.
 __global__ void __launch_bounds__(256) stem_conv_kernel(ConvArgs a, int npix) {
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, h = lane >> 4;
-    const bf16x8 A0 = *reinterpret_cast<const bf16x8*>(a.wgt + l15 * 64 + 8 * h);
-    const bf16x8 A1 = *reinterpret_cast<const bf16x8*>(a.wgt + l15 * 64 + 32 + 8 * h);
+    const half8 A0 = *reinterpret_cast<const half8*>(a.wgt + l15 * 64 + 8 * h);
+    const half8 A1 = *reinterpret_cast<const half8*>(a.wgt + l15 * 64 + 32 + 8 * h);
     const float4 bs = *reinterpret_cast<const float4*>(a.bias + 4 * h);
     const int pitch = (a.W + 2) * 4, hw = a.Ho * a.Wo;                           // elements per framed input row
     // k-step 0: group h = (ky, kx) = (h >> 1, 2 (h & 1)); k-step 1: ky = 2, groups 2 and 3 have zero weights
@@ -279,22 +274,22 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(ConvArgs a, int npix) {
         const int p = (tile0 + i) * 16 + l15;
         const int pc = p < npix ? p : npix - 1;
         const int n = pc / hw, r = pc - n * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
-        const bf16_t* base = a.in + ((size_t)(n * (a.H + 2) + 2 * oy) * (a.W + 2) + 2 * ox) * 4;
-        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(base + off0);
-        const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(base + off1);
+        const half_t* base = a.in + ((size_t)(n * (a.H + 2) + 2 * oy) * (a.W + 2) + 2 * ox) * 4;
+        const half8 B0 = *reinterpret_cast<const half8*>(base + off0);
+        const half8 B1 = *reinterpret_cast<const half8*>(base + off1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, B0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, B1, acc, 0, 0, 0);
         if (p < npix)
-            *reinterpret_cast<ushort4*>(a.out + (size_t)p * a.out_cs + a.out_coff + 4 * h) =
-                make_ushort4(f2bf(silu(acc[0] + bs.x)), f2bf(silu(acc[1] + bs.y)), f2bf(silu(acc[2] + bs.z)), f2bf(silu(acc[3] + bs.w)));
+            *reinterpret_cast<half4*>(a.out + (size_t)p * a.out_cs + a.out_coff + 4 * h) =
+                make_half4(silu(acc[0] + bs.x), silu(acc[1] + bs.y), silu(acc[2] + bs.z), silu(acc[3] + bs.w));
     }
 }
 
-// letterbox + bilinear resize + BGR->RGB + /255 -> NHWC4 bf16 (channel 3 zero) inside a one-pixel frame of zeros:
+// letterbox + bilinear resize + BGR->RGB + /255 -> NHWC4 half (channel 3 zero) inside a one-pixel frame of zeros:
 // [B][H+2][W+2][4], the frame is the stem convolution's padding and is never written
 __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
-                                  int top, int left, bf16_t* __restrict__ out) {
+                                  int top, int left, half_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H * W) return;
     const int n = i / (H * W), r = i - n * H * W, y = r / W, x = r - y * W;
@@ -315,7 +310,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h,
             c[q] = floorf(ta * (1.f - wy) + tb * wy + 0.5f);
         }
     }
-    bf16_t o[4] = {f2bf(c[2] / 255.f), f2bf(c[1] / 255.f), f2bf(c[0] / 255.f), 0};   // RGB
+    half_t o[4] = {f2h(c[2] / 255.f), f2h(c[1] / 255.f), f2h(c[0] / 255.f), (half_t)0};   // RGB
     *reinterpret_cast<uint2*>(out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4) = *reinterpret_cast<const uint2*>(o);
 }
 
@@ -324,7 +319,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ bgr, int B, int h,
 // same), a thread makes two output pixels from 12 contiguous bytes of two rows -- six dword loads instead of 24 byte
 // loads.  Needs w % 4 == 0, a 4-byte aligned frame pointer, even left padding and even nw.
 __global__ void preprocess2_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
-                                   int top, int left, bf16_t* __restrict__ out) {
+                                   int top, int left, half_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, W2 = W >> 1;
     if (i >= B * H * W2) return;
     const int n = i / (H * W2), r = i - n * H * W2, y = r / W2, x = (r - y * W2) * 2;
@@ -351,15 +346,15 @@ __global__ void preprocess2_kernel(const uint8_t* __restrict__ bgr, int B, int h
                 c[o][q] = floorf(ta * (1.f - 0.5f) + tb * 0.5f + 0.5f);
             }
     }
-    bf16_t* dst = out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4;
+    half_t* dst = out + (((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 4;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-        bf16_t v[4] = {f2bf(c[o][2] / 255.f), f2bf(c[o][1] / 255.f), f2bf(c[o][0] / 255.f), 0};   // RGB
+        half_t v[4] = {f2h(c[o][2] / 255.f), f2h(c[o][1] / 255.f), f2h(c[o][0] / 255.f), (half_t)0};   // RGB
         *reinterpret_cast<uint2*>(dst + o * 4) = *reinterpret_cast<const uint2*>(v);
     }
 }
 
-__global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
+__global__ void maxpool5_kernel(const half_t* in, int cs_in, int coff_in, half_t* out, int cs_out, int coff_out, int B,
                                 int H, int W, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * H * W * C) return;
@@ -369,29 +364,28 @@ __global__ void maxpool5_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t
         for (int dx = -2; dx <= 2; ++dx) {
             const int yy = y + dy, xx = x + dx;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            m = fmaxf(m, bf2f(in[((size_t)(n * H + yy) * W + xx) * cs_in + coff_in + c]));
+            m = fmaxf(m, h2f(in[((size_t)(n * H + yy) * W + xx) * cs_in + coff_in + c]));
         }
-    out[(size_t)p * cs_out + coff_out + c] = f2bf(m);
+    out[(size_t)p * cs_out + coff_out + c] = f2h(m);
 }
 
 // SPPF's three chained 5x5/stride-1 max-pools (padding -inf) in one pass: pool(pool(x)) is the 9x9 window of x
 // and the third the 13x13 one, so all three come from one LDS copy of the map, separably (row maxima of
 // radius 2/4/6, then column maxima).  Workgroup = (image, 8-channel slab), thread = pixel, 16-byte accesses.
-__device__ __forceinline__ uint4 bf16x8_max(uint4 a, uint4 b) {
-    auto mx = [](unsigned u, unsigned v) {
-        const float lo = fmaxf(__uint_as_float(u << 16), __uint_as_float(v << 16));
-        const float hi = fmaxf(__uint_as_float(u & 0xFFFF0000u), __uint_as_float(v & 0xFFFF0000u));
-        return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+__device__ __forceinline__ uint4 half8_max(uint4 a, uint4 b) {
+    auto mx = [](unsigned u, unsigned v) {                  // v_pk_max_f16
+        const half2v r = __builtin_elementwise_max(__builtin_bit_cast(half2v, u), __builtin_bit_cast(half2v, v));
+        return __builtin_bit_cast(unsigned, r);
     };
     return make_uint4(mx(a.x, b.x), mx(a.y, b.y), mx(a.z, b.z), mx(a.w, b.w));
 }
-__global__ void __launch_bounds__(1024) sppf_pools_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out,
+__global__ void __launch_bounds__(1024) sppf_pools_kernel(const half_t* in, int cs_in, int coff_in, half_t* out, int cs_out,
                                                           int coff_out, int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
     uint4* s0 = reinterpret_cast<uint4*>(pool_smem);          // [HW] input
     uint4* s1 = s0 + H * W;                                   // [3][HW] row maxima of radius 2, 4, 6
     const int n = blockIdx.x, c8 = blockIdx.y, t = threadIdx.x, HW = H * W;
-    const uint4 NEG = make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);     // bf16 -inf x8
+    const uint4 NEG = make_uint4(0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u);     // half -inf x8
     const int y = t / W, x = t - y * W;
     if (t < HW) s0[t] = *reinterpret_cast<const uint4*>(in + ((size_t)n * HW + t) * cs_in + coff_in + c8 * 8);
     __syncthreads();
@@ -402,9 +396,9 @@ __global__ void __launch_bounds__(1024) sppf_pools_kernel(const bf16_t* in, int 
             if (xx < 0 || xx >= W) continue;
             const uint4 v = s0[y * W + xx];
             const int ad = dx < 0 ? -dx : dx;
-            m6 = bf16x8_max(m6, v);
-            if (ad <= 4) m4 = bf16x8_max(m4, v);
-            if (ad <= 2) m2 = bf16x8_max(m2, v);
+            m6 = half8_max(m6, v);
+            if (ad <= 4) m4 = half8_max(m4, v);
+            if (ad <= 2) m2 = half8_max(m2, v);
         }
         s1[t] = m2, s1[HW + t] = m4, s1[2 * HW + t] = m6;
     }
@@ -417,14 +411,14 @@ __global__ void __launch_bounds__(1024) sppf_pools_kernel(const bf16_t* in, int 
             for (int dy = -r; dy <= r; ++dy) {
                 const int yy = y + dy;
                 if (yy < 0 || yy >= H) continue;
-                m = bf16x8_max(m, s1[k * HW + yy * W + x]);
+                m = half8_max(m, s1[k * HW + yy * W + x]);
             }
             *reinterpret_cast<uint4*>(out + ((size_t)n * HW + t) * cs_out + coff_out + k * C + c8 * 8) = m;
         }
     }
 }
 
-__global__ void upsample2_kernel(const bf16_t* in, int cs_in, int coff_in, bf16_t* out, int cs_out, int coff_out, int B,
+__global__ void upsample2_kernel(const half_t* in, int cs_in, int coff_in, half_t* out, int cs_out, int coff_out, int B,
                                  int H, int W, int C) {   // H, W: input size; output 2H x 2W, nearest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int C8 = C / 8;
@@ -631,7 +625,7 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
 }
 
 // ---- host side: graph of layers --------------------------------------------------------------------------------
-struct Buf { bf16_t* p = nullptr; int C = 0, H = 0, W = 0; };
+struct Buf { half_t* p = nullptr; int C = 0, H = 0, W = 0; };
 struct Slice { int buf, coff, c; };
 
 struct Yolo {
@@ -666,12 +660,12 @@ bool dev_alloc(Yolo& y, void** p, size_t bytes) {
 int new_buf(Yolo& y, int H, int W, int C) {
     Buf b;
     b.C = C, b.H = H, b.W = W;
-    if (!dev_alloc(y, (void**)&b.p, (size_t)y.B * H * W * C * sizeof(bf16_t))) return -1;
+    if (!dev_alloc(y, (void**)&b.p, (size_t)y.B * H * W * C * sizeof(half_t))) return -1;
     y.bufs.push_back(b);
     return (int)y.bufs.size() - 1;
 }
 
-// consumes one conv's parameters, folds BN, uploads bf16 [cout][kpad] + f32 bias, appends the op
+// consumes one conv's parameters, folds BN, uploads half [cout][kpad] + f32 bias, appends the op
 bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* out32, int out32_cs, const Slice* res) {
     const int cin_real = in.c;
     const int cin = in.c, cout = out.c, taps = k * k;
@@ -681,7 +675,7 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     const float* w = y.wsrc + y.wpos;
     const float* bp = w + nw;
     y.wpos += nw + nb;
-    std::vector<bf16_t> wb((size_t)cout * kpad, 0);
+    std::vector<half_t> wb((size_t)cout * kpad, (half_t)0);
     std::vector<float> bias(cout);
     for (int co = 0; co < cout; ++co) {
         float scale = 1.f, sh = bp[co];
@@ -693,9 +687,9 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
         bias[co] = sh;
         for (int ci = 0; ci < cin_real; ++ci)
             for (int t = 0; t < taps; ++t)
-                wb[(size_t)co * kpad + t * cin + ci] = f2bf(w[((size_t)co * cin_real + ci) * taps + t] * scale);
+                wb[(size_t)co * kpad + t * cin + ci] = f2h(w[((size_t)co * cin_real + ci) * taps + t] * scale);
     }
-    bf16_t* dw;
+    half_t* dw;
     float* db;
     if (!dev_alloc(y, (void**)&dw, wb.size() * 2) || !dev_alloc(y, (void**)&db, bias.size() * 4)) return false;
     (void)hipMemcpy(dw, wb.data(), wb.size() * 2, hipMemcpyHostToDevice);
@@ -718,7 +712,7 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     return true;
 }
 
-// the stem's parameters (Conv 3 -> 16, k3 s2, BN, SiLU) packed for stem_conv_kernel: bf16 [16][64], k = ky*16 + kx*4 + c
+// the stem's parameters (Conv 3 -> 16, k3 s2, BN, SiLU) packed for stem_conv_kernel: half [16][64], k = ky*16 + kx*4 + c
 bool add_stem(Yolo& y, Slice in, Slice out) {
     const int cout = 16, cin_real = 3, taps = 9;
     const size_t nw = (size_t)cout * cin_real * taps, nb = 4 * (size_t)cout;
@@ -726,7 +720,7 @@ bool add_stem(Yolo& y, Slice in, Slice out) {
     const float* w = y.wsrc + y.wpos;
     const float* bp = w + nw;
     y.wpos += nw + nb;
-    std::vector<bf16_t> wb((size_t)cout * 64, 0);
+    std::vector<half_t> wb((size_t)cout * 64, (half_t)0);
     std::vector<float> bias(cout);
     for (int co = 0; co < cout; ++co) {
         const float g = bp[co], be = bp[cout + co], mu = bp[2 * cout + co], var = bp[3 * cout + co];
@@ -734,9 +728,9 @@ bool add_stem(Yolo& y, Slice in, Slice out) {
         bias[co] = be - mu * scale;
         for (int ci = 0; ci < cin_real; ++ci)
             for (int t = 0; t < taps; ++t)
-                wb[(size_t)co * 64 + (t / 3) * 16 + (t % 3) * 4 + ci] = f2bf(w[((size_t)co * cin_real + ci) * taps + t] * scale);
+                wb[(size_t)co * 64 + (t / 3) * 16 + (t % 3) * 4 + ci] = f2h(w[((size_t)co * cin_real + ci) * taps + t] * scale);
     }
-    bf16_t* dw;
+    half_t* dw;
     float* db;
     if (!dev_alloc(y, (void**)&dw, wb.size() * 2) || !dev_alloc(y, (void**)&db, bias.size() * 4)) return false;
     (void)hipMemcpy(dw, wb.data(), wb.size() * 2, hipMemcpyHostToDevice);
@@ -914,7 +908,7 @@ int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors) {
     return AV_OK;
 }
 
-// test hook: NHWC bf16 slice of an intermediate tensor (ids follow the yolov8.yaml layer numbers; 0 = input)
+// test hook: NHWC half slice of an intermediate tensor (ids follow the yolov8.yaml layer numbers; 0 = input)
 int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff) {
     AV_REQUIRE(h && ptr && H && W && C && cstride && coff, AV_EINVAL, "av_yolo_tensor: null argument");
     if (id >= 100 && id < 106) {            // head outputs (float32): 100+2i box, 101+2i cls

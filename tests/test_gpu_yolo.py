@@ -34,26 +34,29 @@ def test_preprocess_and_feature_maps(setup):
     t0 = model.tensor(0)                       # RGB inside a one-pixel frame of zeros (the stem's padding)
     assert t0.shape == (386, 642, 3) and not t0[0].any() and not t0[-1].any() and not t0[:, 0].any() and not t0[:, -1].any()
     x = t0[1:-1, 1:-1].transpose(2, 0, 1)
-    assert np.abs(x - R.preprocess(frame)).max() <= 2 ** -8          # bf16 rounding of values in [0,1]
+    assert np.abs(x - R.preprocess(frame)).max() <= 2 ** -11         # half rounding of values in [0,1]
     for tid, key in ((1, "l1"), (2, "l2"), (4, "l4"), (6, "l6"), (8, "l8"), (9, "l9"), (12, "l12"), (15, "p3"),
                      (18, "p4"), (21, "p5")):
         want = feats[key][0].numpy().transpose(1, 2, 0)
         have = model.tensor(tid)
         assert have.shape == want.shape, key
-        assert _rel(have, want) < 0.06, (key, _rel(have, want))       # bf16 activations/weights, fp32 accumulate
-        assert np.abs(have - want).mean() < 0.01 * np.abs(want).mean() + 1e-3, key
+        print("feature map %-4s max err / max |x| = %.5f   mean err / mean |x| = %.5f" % (
+            key, _rel(have, want), np.abs(have - want).mean() / np.abs(want).mean()))
+        assert _rel(have, want) < 0.012, (key, _rel(have, want))      # half activations/weights, fp32 accumulate (bf16: 0.06)
+        assert np.abs(have - want).mean() < 0.002 * np.abs(want).mean() + 1e-4, key
 
 
 def test_head_logits_and_decode(setup):
     Y, R, frame, feats, model, _ = setup
     for i, (b, c) in enumerate(feats["head"]):
         hb, hc = model.tensor(100 + 2 * i), model.tensor(101 + 2 * i)
-        assert _rel(hb, b[0].numpy().transpose(1, 2, 0)) < 0.08
-        assert _rel(hc, c[0].numpy().transpose(1, 2, 0)) < 0.08
+        rb, rc = _rel(hb, b[0].numpy().transpose(1, 2, 0)), _rel(hc, c[0].numpy().transpose(1, 2, 0))
+        print("head level %d: box logits %.5f, class logits %.5f (max err / max |x|)" % (i, rb, rc))
+        assert rb < 0.012 and rc < 0.012                              # bf16: 0.08
 
 
 def test_nms_matches_oracle_on_device_candidates(setup):
-    """NMS is checked on the oracle's own decode of the DEVICE logits, so bf16 noise does not decide selections."""
+    """NMS is checked on the oracle's own decode of the DEVICE logits, so rounding noise does not decide selections."""
     import torch
     Y, R, frame, feats, model, got = setup
     head = []
@@ -71,6 +74,83 @@ def test_nms_matches_oracle_on_device_candidates(setup):
     assert np.all(np.diff(gconf) <= 1e-6)
     assert np.abs(np.sort(gconf)[::-1][:50] - np.sort(conf[keep])[::-1][:50]).max() < 1e-3
     assert boxes.min() >= 0 and boxes[:, [0, 2]].max() <= 1280 and boxes[:, [1, 3]].max() <= 720
+
+
+def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
+    """ObjectDetector(mode="yolo").detect() -- and the 64-frame batch path bench config3 runs -- against the fp32
+    restatement run END TO END on its own logits (decode, NMS, scale_boxes, int()): IoU-matched set equality with
+    +-1 px boxes and a counted allowance for confidence-threshold / NMS flips ("YOLO parity").
+
+    Two parameter sets.  "spread": the random network with the class convolutions rescaled so that confidences
+    spread over (0.01, 0.85) and ~210 of 5040 anchors pass the 0.25 filter -- the regime a trained detector works
+    in; measured flip rate 1.1 % (5 of 442 boxes over six frames; bf16 activations gave 38 %, which is why the
+    library computes in IEEE half).  "random:0" (BASELINE config 3's plain random init): all 5040 confidences lie
+    within 0.03 of each other with a median gap of 6.5e-7 between neighbours in the sorted list, so WHICH 300 boxes
+    survive is decided by rounding noise on either side; there the per-anchor candidates are held to the tolerance
+    instead (every box of every anchor within 0.05 px, confidences within 1e-4) and the flip rate is only reported."""
+    import torch
+    from src.perception import ObjectDetector
+    from tests._util import match_detections, spread_params
+    from tools.yolo_e2e import candidate_stats, report
+    Y, R, frame, feats, model, got = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame] + [synthetic_frame(720, 1280, s, f) for s, f in ((3, 11), (6, 40), (1, 5), (2, 77))]
+    frames.append(np.full((720, 1280, 3), 128, np.uint8))
+    # ---- "spread" parameters: set equality ------------------------------------------------------------------
+    params = spread_params(0)
+    path = str(tmp_path / "spread.npy")
+    np.save(path, params)
+    net = R.build_model(params)
+    det = ObjectDetector(mode="yolo", model_path=path)
+    assert det.mode == "yolo"
+
+    def detect_via_class(fr):
+        out = det.detect(fr)
+        return (np.array([d.bbox for d in out], np.float64).reshape(-1, 4), np.array([d.confidence for d in out]),
+                np.array([d.class_id for d in out], np.int32))
+    rows = report(frames, detect_via_class, R, net, torch, match_detections, px=1.0)
+    flips = sum(r["missing"] + r["extra"] for r in rows)
+    total = sum(r["n_want"] + r["n_got"] for r in rows)
+    print("spread: %d flips of %d boxes (%.2f %%); per frame %s" % (flips, total, 100.0 * flips / total,
+                                                                   [(r["missing"], r["extra"]) for r in rows]))
+    assert total > 300 and flips <= 0.03 * total, rows
+    for r in rows:
+        assert r["matched"] >= 0.85 * r["n_want"] and r["worst_px"] <= 1.0 and r["worst_dconf"] < 2e-3, r
+    # the 64-frame batch path (bench config3): image b of the batch against the oracle's detections of that frame
+    B = 64
+    batched = Y.YoloV8n(path, batch=B)
+    batched._prepare(720, 1280)
+    batched._frames.copy_(torch.as_tensor(np.stack([frames[b % len(frames)] for b in range(B)])))
+    batched.forward_device(batched._frames)
+    torch.cuda.synchronize()
+    n = batched._n.cpu().numpy()
+    box, cls = batched._box.cpu().numpy(), batched._cls.cpu().numpy()
+    it = iter(range(B))
+
+    def detect_from_batch(fr):
+        b = next(it)
+        return box[b, :n[b]], batched._conf[b, :n[b]].cpu().numpy(), cls[b, :n[b]]
+    rows_b = report([frames[b % len(frames)] for b in range(B)][:12] , detect_from_batch, R, net, torch, match_detections, px=1.0)
+    for b in range(B):                                # every copy of a frame inside the batch gives the same detections
+        assert n[b] == n[b % len(frames)] and np.array_equal(box[b, :n[b]], box[b % len(frames), :n[b]]), b
+    fb = sum(r["missing"] + r["extra"] for r in rows_b)
+    assert fb <= 0.03 * sum(r["n_want"] + r["n_got"] for r in rows_b), rows_b
+    batched.close()
+    # per-anchor candidates under the spread parameters
+    msp = Y.YoloV8n(path)
+    for fr in frames[:3]:
+        st = candidate_stats(msp, fr, R, net, torch)
+        assert st["box_max_px"] < 0.05 and st["conf_max"] < 2e-3 and st["class_flips"] <= 10, st
+    msp.close()
+    # ---- plain random init: candidates to tolerance, selection reported ---------------------------------------
+    net0 = R.build_model(R.random_params(0))
+    for fr in frames[:3]:
+        st = candidate_stats(model, fr, R, net0, torch)
+        assert st["box_max_px"] < 0.05 and st["conf_max"] < 1e-4 and st["class_flips"] == 0, st
+    rows0 = report(frames[:3], model.detect, R, net0, torch, match_detections, px=1.0)
+    print("random:0: flip rates %s (confidence gaps of 6.5e-7 decide the selection)" % [round(r["flip_rate"], 3) for r in rows0])
+    for r in rows0:
+        assert r["worst_px"] <= 1.0 and r["matched"] >= 0.3 * r["n_want"], r
 
 
 def test_object_detector_yolo_mode(setup):

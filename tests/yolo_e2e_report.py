@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""python tests/yolo_e2e_report.py [--lib other.so --precision bf16] -- YOLO-mode parity tables, device vs fp32 oracle:
+candidate level (every anchor: box / confidence / class from the device's logits vs the oracle's) and end to end
+(detections after NMS)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", default=None)
+ap.add_argument("--precision", default=None)
+ap.add_argument("--model", default="random:0")
+a = ap.parse_args()
+from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat  # noqa: E402
+if a.lib:
+    nat.LIB_PATH = os.path.abspath(a.lib)
+from multimodal_autonomous_driving_perception_and_planning_amd.perception import yolo as Y  # noqa: E402
+from oracle import yolo_ref as R  # noqa: E402
+from oracle.lane_ref import synthetic_frame  # noqa: E402
+from tests._util import match_detections, spread_params  # noqa: E402
+from tools.yolo_e2e import candidate_stats, report  # noqa: E402
+
+frames = [synthetic_frame(720, 1280, s, f) for s, f in ((0, 0), (3, 11), (6, 40), (1, 5), (2, 77))]
+frames.append(np.full((720, 1280, 3), 128, np.uint8))
+if a.model == "spread":
+    params = spread_params(0)
+    path = "/tmp/avhot_spread.npy"
+    np.save(path, params)
+else:
+    params, path = R.random_params(int(a.model.split(":")[1])), a.model
+net = R.build_model(params)
+model = Y.YoloV8n(path)
+if a.precision:
+    model.precision = a.precision
+print("== candidates (5040 anchors per frame), model %s, precision %s" % (a.model, model.precision))
+for k, fr in enumerate(frames):
+    print(json.dumps(dict(frame=k, **candidate_stats(model, fr, R, net, torch))))
+print("== detections after NMS")
+rows = report(frames, model.detect, R, net, torch, match_detections)
+for r in rows:
+    print(json.dumps(r))
+tot = sum(r["missing"] + r["extra"] for r in rows) / max(1, sum(r["n_want"] + r["n_got"] for r in rows))
+print("overall flip rate %.4f, worst matched |d| %.2f px" % (tot, max(r["worst_px"] for r in rows)))
