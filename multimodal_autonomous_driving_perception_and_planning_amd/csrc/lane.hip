@@ -672,8 +672,195 @@ __global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restric
     }
 }
 
-__device__ __forceinline__ bool all_ones16(const uint4& v) {
-    return v.x == 0x01010101u && v.y == 0x01010101u && v.z == 0x01010101u && v.w == 0x01010101u;
+
+// ---- fused front end: BGR -> gray -> 5x5 blur (+ histogram) -> Sobel -> non-maximum suppression, ONE pass ---------
+// Canny's thresholds come from the median of the whole blurred frame, which is why the reference's order forces the
+// blurred image out to memory and back.  But the thresholds are not needed to decide WHETHER a pixel is a maximum
+// along its gradient, only to classify the maxima afterwards: so this kernel streams a frame once, keeps the blurred
+// rows in a register ring, and writes
+//     nm[y][x] = 0                    if the pixel is not a local maximum along its gradient direction
+//              = min(m / 2, 255)      if it is, m = |gx| + |gy|
+// m is always EVEN (gx and gy are both congruent to the sum of the four corner pixels modulo 2), and the thresholds
+// are at most 255, so "m > lo" == "m/2 > lo/2" and a value saturated at 255 compares like the full magnitude: the
+// hysteresis pass classifies with  candidate = nm > (lo >> 1),  strong = nm > (hi >> 1)  -- exactly cv::Canny's sets.
+// That removes one full-frame write and one read (the blurred image) and the second pass's reloads.
+// Same streaming scheme as the two kernels it replaces (lane = 4 adjacent pixels of a 248-column strip, neighbours
+// by DPP); rows: gray rows feed a 5-deep ring of horizontal sums -> blurred row b -> Sobel of row b-1 -> NMS of row
+// b-2.  Border rules as in OpenCV: reflect-101 for the blur, replicate for Sobel's reads of the blurred image
+// (blurred(-1) == blurred(0): the same register row is pushed again), magnitude 0 outside the image.
+constexpr int FROWS = 72;               // output rows per wave (8 halo rows are recomputed per band)
+
+template <bool KEEP_BLUR>
+__global__ void __launch_bounds__(256) front_stream(const uint8_t* __restrict__ bgr, int h, int w, uint8_t* __restrict__ blur,
+                                                    uint8_t* __restrict__ nm, unsigned* __restrict__ hist) {
+    __shared__ unsigned lh[16 * 256];
+    const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 16 * 256; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int nstrips = (w + SW - 1) / SW, wv = blockIdx.x * 4 + wid;
+    const int strip = wv % nstrips, x0 = strip * SW - 4;
+    const int yb = (wv / nstrips) * FROWS;
+    const int x = x0 + 4 * lane;
+    const bool xin = x >= 0 && x + 4 <= w;
+    const bool out_lane = lane >= 1 && lane <= 62 && xin;
+    const uint8_t* img = bgr + (size_t)s * h * w * 3;
+    const size_t fo = (size_t)s * h * w;
+    if (yb < h) {
+        const int y_end = (yb + FROWS < h ? yb + FROWS : h);
+        const int b_first = yb - 2, b_last = y_end + 1;                  // blurred rows pushed (unclamped indices)
+        const int bc_first = clampi(b_first, h), bc_last = clampi(b_last, h);
+        const int g_last = bc_last + 2;                                   // last gray row consumed (unreflected index)
+        unsigned ra[5] = {0, 0, 0, 0, 0}, rb[5] = {0, 0, 0, 0, 0};       // horizontal sums of the last five gray rows
+        unsigned fa[SPF], fb[SPF], fc[SPF];                              // the next SPF BGR rows, in flight
+        const uint8_t* col = img + (size_t)(xin ? x : 0) * 3;
+        const unsigned pitch = (unsigned)w * 3u;
+        auto fetch = [&](int yy, unsigned& a, unsigned& b, unsigned& c) {
+            const int ys = reflect101_once(yy < g_last ? yy : g_last, h);
+            const unsigned* p = reinterpret_cast<const unsigned*>(col + (size_t)ys * pitch);
+            a = p[0], b = p[1], c = p[2];
+        };
+        int gnext = bc_first - 2;                                        // next gray row to consume
+#pragma unroll
+        for (int q = 0; q < SPF; ++q) fetch(gnext + q, fa[q], fb[q], fc[q]);
+        auto consume_gray = [&]() {
+            unsigned g = 0;
+            const unsigned a = fa[0], b = fb[0], c = fc[0];              // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+#pragma unroll
+            for (int q = 0; q + 1 < SPF; ++q) fa[q] = fa[q + 1], fb[q] = fb[q + 1], fc[q] = fc[q + 1];
+            fetch(gnext + SPF, fa[SPF - 1], fb[SPF - 1], fc[SPF - 1]);
+            ++gnext;
+            if (xin) {
+                const u16x2_t wbg = {1868, 9617};
+                auto gray = [&](unsigned bg_pair, unsigned rr) {
+                    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, bg_pair), wbg, (unsigned)__umul24(4899u, rr) + 8192u, false) >> 14;
+                };
+                const unsigned g0 = gray(__builtin_amdgcn_perm(0u, a, 0x0C010C00u), (a >> 16) & 255u);
+                const unsigned g1 = gray(__builtin_amdgcn_perm(b, a, 0x0C040C03u), (b >> 8) & 255u);
+                const unsigned g2 = gray(__builtin_amdgcn_perm(0u, b, 0x0C030C02u), c & 255u);
+                const unsigned g3 = gray(__builtin_amdgcn_perm(0u, c, 0x0C020C01u), c >> 24);
+                g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+            }
+            unsigned gp = dpp_prev_u32(g), gn = dpp_next_u32(g);
+            if (x == 0) gp = ((g >> 16) & 255u) << 16 | ((g >> 8) & 255u) << 24;          // reflect-101: columns -2,-1 = 2,1
+            if (x + 4 == w) gn = ((g >> 16) & 255u) | (((g >> 8) & 255u) << 8);            // columns w,w+1 = w-2,w-3
+            const unsigned m2 = gp >> 16 & 255u, m1 = gp >> 24, p0 = g & 255u, p1 = (g >> 8) & 255u, p2 = (g >> 16) & 255u,
+                           p3 = g >> 24, n0 = gn & 255u, n1 = (gn >> 8) & 255u;
+            const unsigned h0 = m2 + 4 * m1 + 6 * p0 + 4 * p1 + p2, h1 = m1 + 4 * p0 + 6 * p1 + 4 * p2 + p3;
+            const unsigned h2 = p0 + 4 * p1 + 6 * p2 + 4 * p3 + n0, h3 = p1 + 4 * p2 + 6 * p3 + 4 * n0 + n1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ra[q] = ra[q + 1], rb[q] = rb[q + 1];
+            ra[4] = h0 | (h1 << 16), rb[4] = h2 | (h3 << 16);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) consume_gray();                      // gray rows bc_first-2 .. bc_first+1
+        // Sobel / NMS rings (see sobel_nms_stream): blurred rows, magnitude rows, the middle row's gradients
+        unsigned p02[3] = {0, 0, 0}, p13[3] = {0, 0, 0}, pe[3] = {0, 0, 0};
+        unsigned m02[3] = {0, 0, 0}, m13[3] = {0, 0, 0}, me[3] = {0, 0, 0};
+        unsigned gx02[2] = {0, 0}, gx13[2] = {0, 0}, gy02[2] = {0, 0}, gy13[2] = {0, 0};
+        unsigned c = 0;                                                  // the current blurred row, 4 bytes
+        int prev_bc = bc_first - 1;
+        for (int b = b_first; b <= b_last; ++b) {
+            const int bc = clampi(b, h);
+            if (bc != prev_bc) {                                         // wave-uniform: a new blurred row (not a border replica)
+                consume_gray();                                          // gray row bc + 2
+                const unsigned va = ra[0] + ra[4] + 4u * (ra[1] + ra[3]) + 6u * ra[2] + 0x00800080u;
+                const unsigned vb = rb[0] + rb[4] + 4u * (rb[1] + rb[3]) + 6u * rb[2] + 0x00800080u;
+                const unsigned o0 = (va >> 8) & 255u, o1 = va >> 24, o2 = (vb >> 8) & 255u, o3 = vb >> 24;
+                c = xin ? (o0 | (o1 << 8) | (o2 << 16) | (o3 << 24)) : 0u;
+                if (bc >= yb && bc < y_end && out_lane) {                // this wave owns the row: histogram (+ debug copy)
+                    if (KEEP_BLUR) *reinterpret_cast<unsigned*>(blur + fo + (size_t)bc * w + x) = c;
+                    unsigned* hl = lh + (lane & 15) * 256;
+                    if (o0 == o1 && o1 == o2 && o2 == o3) atomicAdd(&hl[o0], 4u);
+                    else atomicAdd(&hl[o0], 1u), atomicAdd(&hl[o1], 1u), atomicAdd(&hl[o2], 1u), atomicAdd(&hl[o3], 1u);
+                }
+                prev_bc = bc;
+            }
+            // ---- blurred row b enters the ring (replicate at the left / right image border) --------------------
+            unsigned lft = dpp_prev_u32(c) >> 24, rgt = dpp_next_u32(c) & 255u;
+            if (x == 0) lft = c & 255u;
+            if (x + 4 == w) rgt = c >> 24;
+            p02[0] = p02[1], p02[1] = p02[2], p02[2] = c & 0x00FF00FFu;
+            p13[0] = p13[1], p13[1] = p13[2], p13[2] = (c >> 8) & 0x00FF00FFu;
+            pe[0] = pe[1], pe[1] = pe[2], pe[2] = lft | (rgt << 16);
+            // ---- Sobel of row b-1 ---------------------------------------------------------------------------------
+            const int ym = b - 1;
+            m02[0] = m02[1], m02[1] = m02[2], m13[0] = m13[1], m13[1] = m13[2], me[0] = me[1], me[1] = me[2];
+            gx02[0] = gx02[1], gx13[0] = gx13[1], gy02[0] = gy02[1], gy13[0] = gy13[1];
+            {
+                const unsigned v02 = p02[0] + 2u * p02[1] + p02[2], v13 = p13[0] + 2u * p13[1] + p13[2], ve = pe[0] + 2u * pe[1] + pe[2];
+                const unsigned d02 = pk_sub16(p02[2], p02[0]), d13 = pk_sub16(p13[2], p13[0]), de = pk_sub16(pe[2], pe[0]);
+                const unsigned dx02 = pk_sub16(v13, (ve & 0xFFFFu) | (v13 << 16));
+                const unsigned dx13 = pk_sub16((v02 >> 16) | (ve & 0xFFFF0000u), v02);
+                const unsigned dy02 = pk_add16(pk_add16((de & 0xFFFFu) | (d13 << 16), pk_add16(d02, d02)), d13);
+                const unsigned dy13 = pk_add16(pk_add16(d02, pk_add16(d13, d13)), (d02 >> 16) | (de & 0xFFFF0000u));
+                gx02[1] = dx02, gx13[1] = dx13, gy02[1] = dy02, gy13[1] = dy13;
+                const bool in = ym >= 0 && ym < h && xin;
+                m02[2] = in ? pk_abs16(dx02) + pk_abs16(dy02) : 0u;
+                m13[2] = in ? pk_abs16(dx13) + pk_abs16(dy13) : 0u;
+                me[2] = (dpp_prev_u32(m13[2]) >> 16) | (dpp_next_u32(m02[2]) << 16);
+            }
+            // ---- NMS of row b-2 -----------------------------------------------------------------------------------
+            const int yo = b - 2;
+            if (yo >= yb && yo < y_end && out_lane) {
+                unsigned o = 0;
+                if ((m02[1] | m13[1]) != 0u) {
+                    int mm[3][6];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        mm[q][0] = (int)(me[q] & 0xFFFFu), mm[q][5] = (int)(me[q] >> 16);
+                        mm[q][1] = (int)(m02[q] & 0xFFFFu), mm[q][3] = (int)(m02[q] >> 16);
+                        mm[q][2] = (int)(m13[q] & 0xFFFFu), mm[q][4] = (int)(m13[q] >> 16);
+                    }
+                    const int gxs[4] = {(int)(short)(gx02[0] & 0xFFFFu), (int)(short)(gx13[0] & 0xFFFFu), (int)(short)(gx02[0] >> 16),
+                                        (int)(short)(gx13[0] >> 16)};
+                    const int gys[4] = {(int)(short)(gy02[0] & 0xFFFFu), (int)(short)(gy13[0] & 0xFFFFu), (int)(short)(gy02[0] >> 16),
+                                        (int)(short)(gy13[0] >> 16)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = mm[1][k + 1];
+                        const int xs = gxs[k], ysg = gys[k];
+                        const int ax = abs(xs), ay = abs(ysg) << 15;
+                        const int tg22x = __mul24(ax, 13573);                    // |gx| <= 1020
+                        const int tg67x = tg22x + (ax << 16);
+                        const bool neg = (xs ^ ysg) < 0;
+                        // the two neighbours along the gradient, and whether the second comparison is strict
+                        const bool hz = ay < tg22x, vt = ay > tg67x;
+                        const int n1 = hz ? mm[1][k] : (vt ? mm[0][k + 1] : (neg ? mm[0][k + 2] : mm[0][k]));
+                        const int n2 = hz ? mm[1][k + 2] : (vt ? mm[2][k + 1] : (neg ? mm[2][k] : mm[2][k + 2]));
+                        const bool is_max = m > n1 && (m > n2 || ((hz || vt) && m == n2));
+                        const unsigned code = (unsigned)min(m >> 1, 255);
+                        o |= (is_max ? code : 0u) << (8 * k);
+                    }
+                }
+                *reinterpret_cast<unsigned*>(nm + fo + (size_t)yo * w + x) = o;
+            }
+        }
+    }
+    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += lh[q * 256 + tid];
+    if (tot) atomicAdd(&hist[(size_t)s * 256 + tid], tot);
+}
+
+// candidate / strong bits of 16 map bytes.  NM: the fused front end's non-maximum-suppressed magnitudes against the
+// halved thresholds; otherwise the {0 weak, 1 none, 2 strong} codes of the two-pass kernels.
+template <bool NM>
+__device__ __forceinline__ void map_bits(const uint4& v, int lo2, int hi2, unsigned& cand, unsigned& strong) {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+    cand = 0, strong = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (NM) cand |= ((int)b[k] > lo2 ? 1u : 0u) << k, strong |= ((int)b[k] > hi2 ? 1u : 0u) << k;
+        else cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
+    }
+}
+template <bool NM>
+__device__ __forceinline__ bool map_cand(uint8_t v, int lo2) { return NM ? (int)v > lo2 : v != 1; }
+__device__ __forceinline__ void half_thresholds(const double* thr, int s, int& lo2, int& hi2) {
+    int lo = (int)thr[(size_t)s * 4], hi = (int)thr[(size_t)s * 4 + 1];
+    if (lo > hi) { const int q = lo; lo = hi; hi = q; }
+    lo2 = lo >> 1, hi2 = hi >> 1;
 }
 
 // Chunk index inside a frame -> (row, first column) without an integer division: float reciprocal, then the
@@ -726,13 +913,16 @@ __device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4
     out[3] = cand & ~UCm & URm & ~Rm;
 }
 
+template <bool NM>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,
-                                                       unsigned* __restrict__ labels_all) {
+                                                       const double* __restrict__ thr, unsigned* __restrict__ labels_all) {
     __shared__ unsigned lab[CT_PX];               // local label: pixel index inside the tile (row * 256 + column), bit 31 = weak
     __shared__ unsigned cm[CT_NCH];               // per 16-pixel chunk: candidate bits | strong bits << 16
     const int tid = threadIdx.x, x0 = blockIdx.x * CT_C, y0 = blockIdx.y * CT_R, s = blockIdx.z;
     const uint8_t* m = map_all + (size_t)s * h * w;
     unsigned* glab = labels_all + (size_t)s * h * w;
+    int lo2 = 0, hi2 = 0;
+    if (NM) half_thresholds(thr, s, lo2, hi2);
     constexpr int Q = CT_NCH / 256;
     unsigned candq[Q];
     bool any = false;
@@ -740,12 +930,11 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
     for (int q = 0; q < Q; ++q) {
         const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
         const int y = y0 + r, x = x0 + cc * 16;
-        uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        const unsigned none = NM ? 0u : 0x01010101u;
+        uint4 v = make_uint4(none, none, none, none);
         if (y < h && x < w) v = *reinterpret_cast<const uint4*>(m + (size_t)y * w + x);          // w % 16 == 0
-        unsigned cand = 0, strong = 0;
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
+        unsigned cand, strong;
+        map_bits<NM>(v, lo2, hi2, cand, strong);
         candq[q] = cand;
         cm[c] = cand | strong << 16;
         any = any || cand != 0;
@@ -811,12 +1000,15 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
 // Links across tile borders, with global unions.  blockIdx.y < nbh: the horizontal border above row (blockIdx.y+1)*16,
 // one thread per column; else the vertical border left of column (blockIdx.y-nbh+1)*256, one thread per row.  Same
 // skipping rules as inside the tiles, here with every neighbour's true candidate bit.
+template <bool NM>
 __global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restrict__ map_all, int h, int w, int nbh,
-                                                         unsigned* __restrict__ labels_all) {
+                                                         const double* __restrict__ thr, unsigned* __restrict__ labels_all) {
     const int s = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
     const uint8_t* m = map_all + (size_t)s * h * w;
     unsigned* lab = labels_all + (size_t)s * h * w;
-    auto cand = [&](int y, int x) { return y >= 0 && x >= 0 && x < w && m[(size_t)y * w + x] != 1; };
+    int lo2 = 0, hi2 = 0;
+    if (NM) half_thresholds(thr, s, lo2, hi2);
+    auto cand = [&](int y, int x) { return y >= 0 && x >= 0 && x < w && map_cand<NM>(m[(size_t)y * w + x], lo2); };
     if ((int)blockIdx.y < nbh) {
         const int y = ((int)blockIdx.y + 1) * CT_R, x = i;
         if (x >= w || !cand(y, x)) return;
@@ -842,40 +1034,56 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restri
 
 // Resolve every candidate's component (strong root = an edge), apply the ROI, count the ROI edges per row.
 // A thread takes FCK 16-pixel chunks a workgroup-stride apart (coalesced per trip, loads in flight together).
+// Only the box of chunks [bx0, bx0 + bcw) x [by0, by0 + bch) is visited: the whole frame when the pre-ROI edge map is
+// wanted or the ROI is caller-defined, else the bounding box of the default trapezoid -- outside it the masked map
+// is never written by anybody (it is zero since av_lane_workspace_init and the Hough stage only erases).
 constexpr int FCK = 4;
+template <bool NM>
 __global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map_all, int h, int w,
-                                                     unsigned* __restrict__ labels_all, Roi roi,
+                                                     const double* __restrict__ thr, unsigned* __restrict__ labels_all, Roi roi,
                                                      const int* __restrict__ roi_rows, uint8_t* __restrict__ edges_all,
-                                                     uint8_t* __restrict__ masked_all, int* __restrict__ rowcnt) {
-    const int cw = w >> 4, s = blockIdx.y;
-    const float rcw = 1.0f / (float)cw;
-    const unsigned total = (unsigned)(h * cw);
+                                                     uint8_t* __restrict__ masked_all, int* __restrict__ rowcnt, int bx0,
+                                                     int by0, int bcw, int bch) {
+    const int s = blockIdx.y;
+    const float rcw = 1.0f / (float)bcw;
+    const unsigned total = (unsigned)(bch * bcw);
     const unsigned c0 = blockIdx.x * (256u * FCK) + threadIdx.x;
     const size_t fo = (size_t)s * h * w;
     const uint8_t* m = map_all + fo;
     unsigned* lab = labels_all + fo;
+    int lo2 = 0, hi2 = 0;
+    if (NM) half_thresholds(thr, s, lo2, hi2);
     uint4 cur4[FCK];
+    int yy[FCK], xx0[FCK];
 #pragma unroll
     for (int g = 0; g < FCK; ++g) {
         const unsigned ci = c0 + (unsigned)g * 256u;
-        cur4[g] = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        if (ci < total) cur4[g] = *reinterpret_cast<const uint4*>(m + (size_t)ci * 16);
+        const unsigned none = NM ? 0u : 0x01010101u;
+        cur4[g] = make_uint4(none, none, none, none);
+        yy[g] = 0, xx0[g] = 0;
+        if (ci < total) {
+            int y, xb;
+            chunk_xy(ci, bcw, rcw, y, xb);
+            yy[g] = by0 + y, xx0[g] = bx0 * 16 + xb;
+            cur4[g] = *reinterpret_cast<const uint4*>(m + (size_t)yy[g] * w + xx0[g]);
+        }
     }
 #pragma unroll
     for (int g = 0; g < FCK; ++g) {
         const unsigned ci = c0 + (unsigned)g * 256u;
         if (ci >= total) break;
         uint4 e4 = make_uint4(0, 0, 0, 0), k4 = e4;
-        if (!all_ones16(cur4[g])) {
-            int y, xb, xl, xr, cnt = 0;
-            chunk_xy(ci, cw, rcw, y, xb);
+        unsigned candm, strongm;
+        map_bits<NM>(cur4[g], lo2, hi2, candm, strongm);
+        const int y = yy[g], xb = xx0[g];
+        if (candm) {
+            int xl, xr, cnt = 0;
             roi_bounds(roi, h, y, roi_rows, xl, xr);
-            const uint8_t* cur = reinterpret_cast<const uint8_t*>(&cur4[g]);
             uint8_t* e = reinterpret_cast<uint8_t*>(&e4);
             uint8_t* k = reinterpret_cast<uint8_t*>(&k4);
             bool run_on = false, keep = false;               // adjacent candidates share their component: one find per run
             for (int q = 0; q < 16; ++q) {
-                if (cur[q] == 1) {
+                if (!((candm >> q) & 1u)) {
                     run_on = false;
                     continue;
                 }
@@ -888,8 +1096,9 @@ __global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__
             }
             if (cnt) atomicAdd(&rowcnt[(size_t)s * h + y], cnt);
         }
-        if (edges_all) *reinterpret_cast<uint4*>(edges_all + fo + (size_t)ci * 16) = e4;
-        *reinterpret_cast<uint4*>(masked_all + fo + (size_t)ci * 16) = k4;
+        const size_t off = fo + (size_t)y * w + xb;
+        if (edges_all) *reinterpret_cast<uint4*>(edges_all + off) = e4;
+        *reinterpret_cast<uint4*>(masked_all + off) = k4;
     }
 }
 
@@ -2016,36 +2225,64 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
     const bool streamp = (w % 4 == 0) && w >= 8 && (((size_t)bgr | (size_t)workspace) & 15) == 0 && !(stages & 4);
     if (!(stages & 16)) {                                          // bit 4: Hough + fit only, on the point lists already in the workspace
-        const dim3 sgrid((((w + SW - 1) / SW) * ((h + SROWS - 1) / SROWS) + 3) / 4, 1, n_streams);      // waves = strips x bands
-        if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
-        else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
-        else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
-        AV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
-        AV_LAUNCH_CHECK();
-        if (streamp) hipLaunchKernelGGL(sobel_nms_stream, sgrid, dim3(256), 0, st, blur, h, w, thr, map, labels);
-        else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
-        else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
-        AV_LAUNCH_CHECK();
-        const unsigned fchunks = (unsigned)h * (unsigned)(w >> 4);                 // 16-pixel chunks of one frame
-        if (fastp) {
-            hipLaunchKernelGGL(ccl_tile_kernel, dim3((w + CT_C - 1) / CT_C, (h + CT_R - 1) / CT_R, n_streams), dim3(256), 0, st, map,
-                               h, w, labels);
-            const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
-            if (nbh + nbv > 0)
-                hipLaunchKernelGGL(ccl_border_kernel, dim3((span + 255) / 256, nbh + nbv, n_streams), dim3(256), 0, st, map, h, w,
-                                   nbh, labels);
-        } else hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
-        AV_LAUNCH_CHECK();
+        // fused = one streaming pass BGR -> non-maximum-suppressed magnitudes (thresholds applied by the hysteresis pass);
+        // other shapes take the two-pass kernels with the blurred image in memory between them
+        const bool fused = streamp && fastp && !getenv("AVHOT_LANE_TWO_PASS");
+        if (fused) {
+            const dim3 fgrid((((w + SW - 1) / SW) * ((h + FROWS - 1) / FROWS) + 3) / 4, 1, n_streams);     // waves = strips x bands
+            if (stages & 1) hipLaunchKernelGGL(front_stream<true>, fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else hipLaunchKernelGGL(front_stream<false>, fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            AV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
+            AV_LAUNCH_CHECK();
+        } else {
+            const dim3 sgrid((((w + SW - 1) / SW) * ((h + SROWS - 1) / SROWS) + 3) / 4, 1, n_streams);      // waves = strips x bands
+            if (streamp) hipLaunchKernelGGL(gray_blur_hist_stream, sgrid, dim3(256), 0, st, bgr, h, w, blur, hist);
+            else if (fastp) hipLaunchKernelGGL(gray_blur_hist_fast, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+            else hipLaunchKernelGGL(gray_blur_hist_kernel, tiles, dim3(256), 0, st, bgr, h, w, blur, hist);
+            AV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
+            AV_LAUNCH_CHECK();
+            if (streamp) hipLaunchKernelGGL(sobel_nms_stream, sgrid, dim3(256), 0, st, blur, h, w, thr, map, labels);
+            else if (fastp) hipLaunchKernelGGL(sobel_nms_fast, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+            else hipLaunchKernelGGL(sobel_nms_kernel, tiles, dim3(256), 0, st, blur, h, w, thr, map, labels);
+            AV_LAUNCH_CHECK();
+        }
         Roi roi;
         roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
         roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
-        if (fastp)
-            hipLaunchKernelGGL(finalize_fast, dim3((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams), dim3(256), 0, st, map, h, w,
-                               labels, roi, roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
-        else
+        if (fastp) {
+            const dim3 tgrid((w + CT_C - 1) / CT_C, (h + CT_R - 1) / CT_R, n_streams);
+            if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
+            else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
+            const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
+            if (nbh + nbv > 0) {
+                const dim3 bgrid((span + 255) / 256, nbh + nbv, n_streams);
+                if (fused) hipLaunchKernelGGL(ccl_border_kernel<true>, bgrid, dim3(256), 0, st, map, h, w, nbh, thr, labels);
+                else hipLaunchKernelGGL(ccl_border_kernel<false>, bgrid, dim3(256), 0, st, map, h, w, nbh, thr, labels);
+            }
+            AV_LAUNCH_CHECK();
+            // chunk box the resolve pass visits: everything for the debug edge map or a caller-defined ROI, else the
+            // default trapezoid's bounding box (rows yt .. h-1, columns x0 .. x3)
+            int bx0 = 0, by0 = 0, bcw = w >> 4, bch = h;
+            if (!(stages & 1) && !roi_rows) {
+                by0 = roi.yt < h ? roi.yt : h - 1, bch = h - by0;
+                bx0 = roi.x0 >> 4, bcw = (((roi.x3 < w ? roi.x3 : w - 1) >> 4) - bx0) + 1;
+            }
+            const unsigned fchunks = (unsigned)bch * (unsigned)bcw;
+            const dim3 ngrid((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams);
+            if (fused)
+                hipLaunchKernelGGL(finalize_fast<true>, ngrid, dim3(256), 0, st, map, h, w, thr, labels, roi, roi_rows,
+                                   (stages & 1) ? edges : nullptr, masked, rowcnt, bx0, by0, bcw, bch);
+            else
+                hipLaunchKernelGGL(finalize_fast<false>, ngrid, dim3(256), 0, st, map, h, w, thr, labels, roi, roi_rows,
+                                   (stages & 1) ? edges : nullptr, masked, rowcnt, bx0, by0, bcw, bch);
+        } else {
+            hipLaunchKernelGGL(ccl_merge_kernel, dim3((w + 63) / 64, (h + 3) / 4, n_streams), dim3(256), 0, st, map, h, w, labels);
+            AV_LAUNCH_CHECK();
             hipLaunchKernelGGL(finalize_kernel, dim3((w + 1023) / 1024, h, n_streams), dim3(256), 0, st, map, h, w, labels, roi,
                                roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
+        }
         AV_LAUNCH_CHECK();
         hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
         AV_LAUNCH_CHECK();
