@@ -688,13 +688,50 @@ __global__ void __launch_bounds__(256) sobel_nms_stream(const uint8_t* __restric
 // by DPP); rows: gray rows feed a 5-deep ring of horizontal sums -> blurred row b -> Sobel of row b-1 -> NMS of row
 // b-2.  Border rules as in OpenCV: reflect-101 for the blur, replicate for Sobel's reads of the blurred image
 // (blurred(-1) == blurred(0): the same register row is pushed again), magnitude 0 outside the image.
-constexpr int FROWS = 72;               // output rows per wave (8 halo rows are recomputed per band)
+// output rows per wave: a template parameter (8 halo rows are recomputed per band; 45 gives 1280x720 frames 16 bands)
 
-template <bool KEEP_BLUR>
+// packed 16-bit helpers (VOP3P): a register holds two pixels, X02 = (x0 | x2 << 16), X13 = (x1 | x3 << 16) -- with this
+// interleaving the right neighbours of pixels (0,2) are exactly register X13 and the left neighbours of (1,3) exactly X02
+__device__ __forceinline__ unsigned pk_addu(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b));
+}
+__device__ __forceinline__ unsigned pk_mulu(unsigned a, unsigned short k) {
+    const u16x2_t kk = {k, k};
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) * kk);
+}
+__device__ __forceinline__ unsigned pk_shru(unsigned a, int n) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) >> (unsigned short)n);
+}
+__device__ __forceinline__ unsigned pk_shlu(unsigned a, int n) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) << (unsigned short)n);
+}
+__device__ __forceinline__ unsigned pk_sar15(unsigned a) {            // 0xFFFF where the half is negative, else 0
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2_t, a) >> (short)15);
+}
+__device__ __forceinline__ unsigned pk_subsat(unsigned a, unsigned b) {      // max(a - b, 0) per half
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+// 16-bit halves of two registers -> one pair (v_perm_b32: selector bytes 0-3 = second operand, 4-7 = first)
+__device__ __forceinline__ unsigned lo_lo(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x05040100u); }   // x.lo | y.lo << 16
+__device__ __forceinline__ unsigned hi_lo(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x05040302u); }   // x.hi | y.lo << 16
+__device__ __forceinline__ unsigned lo_hi(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x07060100u); }   // x.lo | y.hi << 16
+__device__ __forceinline__ unsigned hi_hi(unsigned x, unsigned y) { return __builtin_amdgcn_perm(y, x, 0x07060302u); }   // x.hi | y.hi << 16
+__device__ __forceinline__ unsigned bsel(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }     // v_bfi_b32
+// hides where a mask came from: otherwise the compiler turns sign-mask + v_bfi back into per-half compares and selects
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <bool KEEP_BLUR, int FROWS>
 __global__ void __launch_bounds__(256) front_stream(const uint8_t* __restrict__ bgr, int h, int w, uint8_t* __restrict__ blur,
                                                     uint8_t* __restrict__ nm, unsigned* __restrict__ hist) {
     __shared__ unsigned lh[16 * 256];
-    const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int s = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: rows, bounds and row tests stay scalar
     for (int i = tid; i < 16 * 256; i += 256) lh[i] = 0;
     __syncthreads();
     const int nstrips = (w + SW - 1) / SW, wv = blockIdx.x * 4 + wid;
@@ -703,33 +740,41 @@ __global__ void __launch_bounds__(256) front_stream(const uint8_t* __restrict__ 
     const int x = x0 + 4 * lane;
     const bool xin = x >= 0 && x + 4 <= w;
     const bool out_lane = lane >= 1 && lane <= 62 && xin;
+    const bool at_left = x == 0, at_right = x + 4 == w;
+    const unsigned lane_mask = xin ? 0xFFFFFFFFu : 0u;
     const uint8_t* img = bgr + (size_t)s * h * w * 3;
     const size_t fo = (size_t)s * h * w;
     if (yb < h) {
         const int y_end = (yb + FROWS < h ? yb + FROWS : h);
-        const int b_first = yb - 2, b_last = y_end + 1;                  // blurred rows pushed (unclamped indices)
-        const int bc_first = clampi(b_first, h), bc_last = clampi(b_last, h);
-        const int g_last = bc_last + 2;                                   // last gray row consumed (unreflected index)
-        unsigned ra[5] = {0, 0, 0, 0, 0}, rb[5] = {0, 0, 0, 0, 0};       // horizontal sums of the last five gray rows
-        unsigned fa[SPF], fb[SPF], fc[SPF];                              // the next SPF BGR rows, in flight
+        // Iteration r consumes gray row r (reflect-101) and completes: horizontal sums H[r], U[r-1] = H[r-2] + 2 H[r-1] + H[r],
+        // blurred row b = r-2 = (U[r-3] + 2 U[r-2] + U[r-1] + 128) >> 8   ((1 2 1) * (1 2 1) = 1 4 6 4 1),
+        // Sobel + direction class of row r-3, NMS of row r-4.  Every ring is three deep and the loop is unrolled by
+        // three, so ring slots are compile-time registers and nothing is ever moved.
+        const int r_first = yb - 4, r_last = y_end + 3;
+        unsigned H02[3] = {0, 0, 0}, H13[3] = {0, 0, 0}, U02[3] = {0, 0, 0}, U13[3] = {0, 0, 0};
+        unsigned P02[3] = {0, 0, 0}, P13[3] = {0, 0, 0}, PE[3] = {0, 0, 0};
+        unsigned M02[3] = {0, 0, 0}, M13[3] = {0, 0, 0}, ME[3] = {0, 0, 0};
+        unsigned HZ02[3] = {0, 0, 0}, HZ13[3] = {0, 0, 0}, VT02[3] = {0, 0, 0}, VT13[3] = {0, 0, 0}, NG02[3] = {0, 0, 0},
+                 NG13[3] = {0, 0, 0};
+        unsigned fa[3], fb[3], fc[3];                                    // the next three BGR rows, in flight
         const uint8_t* col = img + (size_t)(xin ? x : 0) * 3;
         const unsigned pitch = (unsigned)w * 3u;
         auto fetch = [&](int yy, unsigned& a, unsigned& b, unsigned& c) {
-            const int ys = reflect101_once(yy < g_last ? yy : g_last, h);
+            const int ys = reflect101_once(yy < r_last ? yy : r_last, h);
             const unsigned* p = reinterpret_cast<const unsigned*>(col + (size_t)ys * pitch);
             a = p[0], b = p[1], c = p[2];
         };
-        int gnext = bc_first - 2;                                        // next gray row to consume
 #pragma unroll
-        for (int q = 0; q < SPF; ++q) fetch(gnext + q, fa[q], fb[q], fc[q]);
-        auto consume_gray = [&]() {
-            unsigned g = 0;
-            const unsigned a = fa[0], b = fb[0], c = fc[0];              // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+        for (int q = 0; q < 3; ++q) fetch(r_first + q, fa[q], fb[q], fc[q]);
+        unsigned* hl = lh + (lane & 15) * 256;
+        for (int r0 = r_first; r0 <= r_last; r0 += 3) {
 #pragma unroll
-            for (int q = 0; q + 1 < SPF; ++q) fa[q] = fa[q + 1], fb[q] = fb[q + 1], fc[q] = fc[q + 1];
-            fetch(gnext + SPF, fa[SPF - 1], fb[SPF - 1], fc[SPF - 1]);
-            ++gnext;
-            if (xin) {
+            for (int k = 0; k < 3; ++k) {
+                const int r = r0 + k;                                    // (up to two rows past r_last: nothing they produce is kept)
+                const int k1 = (k + 2) % 3, k2 = (k + 1) % 3;            // slots of the previous and the one before
+                // ---- gray row r: 4 pixels -> pairs G02, G13 -----------------------------------------------------
+                const unsigned a = fa[k], b = fb[k], c = fc[k];          // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                fetch(r + 3, fa[k], fb[k], fc[k]);
                 const u16x2_t wbg = {1868, 9617};
                 auto gray = [&](unsigned bg_pair, unsigned rr) {
                     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, bg_pair), wbg, (unsigned)__umul24(4899u, rr) + 8192u, false) >> 14;
@@ -738,101 +783,93 @@ __global__ void __launch_bounds__(256) front_stream(const uint8_t* __restrict__ 
                 const unsigned g1 = gray(__builtin_amdgcn_perm(b, a, 0x0C040C03u), (b >> 8) & 255u);
                 const unsigned g2 = gray(__builtin_amdgcn_perm(0u, b, 0x0C030C02u), c & 255u);
                 const unsigned g3 = gray(__builtin_amdgcn_perm(0u, c, 0x0C020C01u), c >> 24);
-                g = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-            }
-            unsigned gp = dpp_prev_u32(g), gn = dpp_next_u32(g);
-            if (x == 0) gp = ((g >> 16) & 255u) << 16 | ((g >> 8) & 255u) << 24;          // reflect-101: columns -2,-1 = 2,1
-            if (x + 4 == w) gn = ((g >> 16) & 255u) | (((g >> 8) & 255u) << 8);            // columns w,w+1 = w-2,w-3
-            const unsigned m2 = gp >> 16 & 255u, m1 = gp >> 24, p0 = g & 255u, p1 = (g >> 8) & 255u, p2 = (g >> 16) & 255u,
-                           p3 = g >> 24, n0 = gn & 255u, n1 = (gn >> 8) & 255u;
-            const unsigned h0 = m2 + 4 * m1 + 6 * p0 + 4 * p1 + p2, h1 = m1 + 4 * p0 + 6 * p1 + 4 * p2 + p3;
-            const unsigned h2 = p0 + 4 * p1 + 6 * p2 + 4 * p3 + n0, h3 = p1 + 4 * p2 + 6 * p3 + 4 * n0 + n1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ra[q] = ra[q + 1], rb[q] = rb[q + 1];
-            ra[4] = h0 | (h1 << 16), rb[4] = h2 | (h3 << 16);
-        };
-#pragma unroll
-        for (int q = 0; q < 4; ++q) consume_gray();                      // gray rows bc_first-2 .. bc_first+1
-        // Sobel / NMS rings (see sobel_nms_stream): blurred rows, magnitude rows, the middle row's gradients
-        unsigned p02[3] = {0, 0, 0}, p13[3] = {0, 0, 0}, pe[3] = {0, 0, 0};
-        unsigned m02[3] = {0, 0, 0}, m13[3] = {0, 0, 0}, me[3] = {0, 0, 0};
-        unsigned gx02[2] = {0, 0}, gx13[2] = {0, 0}, gy02[2] = {0, 0}, gy13[2] = {0, 0};
-        unsigned c = 0;                                                  // the current blurred row, 4 bytes
-        int prev_bc = bc_first - 1;
-        for (int b = b_first; b <= b_last; ++b) {
-            const int bc = clampi(b, h);
-            if (bc != prev_bc) {                                         // wave-uniform: a new blurred row (not a border replica)
-                consume_gray();                                          // gray row bc + 2
-                const unsigned va = ra[0] + ra[4] + 4u * (ra[1] + ra[3]) + 6u * ra[2] + 0x00800080u;
-                const unsigned vb = rb[0] + rb[4] + 4u * (rb[1] + rb[3]) + 6u * rb[2] + 0x00800080u;
-                const unsigned o0 = (va >> 8) & 255u, o1 = va >> 24, o2 = (vb >> 8) & 255u, o3 = vb >> 24;
-                c = xin ? (o0 | (o1 << 8) | (o2 << 16) | (o3 << 24)) : 0u;
-                if (bc >= yb && bc < y_end && out_lane) {                // this wave owns the row: histogram (+ debug copy)
-                    if (KEEP_BLUR) *reinterpret_cast<unsigned*>(blur + fo + (size_t)bc * w + x) = c;
-                    unsigned* hl = lh + (lane & 15) * 256;
-                    if (o0 == o1 && o1 == o2 && o2 == o3) atomicAdd(&hl[o0], 4u);
-                    else atomicAdd(&hl[o0], 1u), atomicAdd(&hl[o1], 1u), atomicAdd(&hl[o2], 1u), atomicAdd(&hl[o3], 1u);
-                }
-                prev_bc = bc;
-            }
-            // ---- blurred row b enters the ring (replicate at the left / right image border) --------------------
-            unsigned lft = dpp_prev_u32(c) >> 24, rgt = dpp_next_u32(c) & 255u;
-            if (x == 0) lft = c & 255u;
-            if (x + 4 == w) rgt = c >> 24;
-            p02[0] = p02[1], p02[1] = p02[2], p02[2] = c & 0x00FF00FFu;
-            p13[0] = p13[1], p13[1] = p13[2], p13[2] = (c >> 8) & 0x00FF00FFu;
-            pe[0] = pe[1], pe[1] = pe[2], pe[2] = lft | (rgt << 16);
-            // ---- Sobel of row b-1 ---------------------------------------------------------------------------------
-            const int ym = b - 1;
-            m02[0] = m02[1], m02[1] = m02[2], m13[0] = m13[1], m13[1] = m13[2], me[0] = me[1], me[1] = me[2];
-            gx02[0] = gx02[1], gx13[0] = gx13[1], gy02[0] = gy02[1], gy13[0] = gy13[1];
-            {
-                const unsigned v02 = p02[0] + 2u * p02[1] + p02[2], v13 = p13[0] + 2u * p13[1] + p13[2], ve = pe[0] + 2u * pe[1] + pe[2];
-                const unsigned d02 = pk_sub16(p02[2], p02[0]), d13 = pk_sub16(p13[2], p13[0]), de = pk_sub16(pe[2], pe[0]);
-                const unsigned dx02 = pk_sub16(v13, (ve & 0xFFFFu) | (v13 << 16));
-                const unsigned dx13 = pk_sub16((v02 >> 16) | (ve & 0xFFFF0000u), v02);
-                const unsigned dy02 = pk_add16(pk_add16((de & 0xFFFFu) | (d13 << 16), pk_add16(d02, d02)), d13);
-                const unsigned dy13 = pk_add16(pk_add16(d02, pk_add16(d13, d13)), (d02 >> 16) | (de & 0xFFFF0000u));
-                gx02[1] = dx02, gx13[1] = dx13, gy02[1] = dy02, gy13[1] = dy13;
-                const bool in = ym >= 0 && ym < h && xin;
-                m02[2] = in ? pk_abs16(dx02) + pk_abs16(dy02) : 0u;
-                m13[2] = in ? pk_abs16(dx13) + pk_abs16(dy13) : 0u;
-                me[2] = (dpp_prev_u32(m13[2]) >> 16) | (dpp_next_u32(m02[2]) << 16);
-            }
-            // ---- NMS of row b-2 -----------------------------------------------------------------------------------
-            const int yo = b - 2;
-            if (yo >= yb && yo < y_end && out_lane) {
-                unsigned o = 0;
-                if ((m02[1] | m13[1]) != 0u) {
-                    int mm[3][6];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        mm[q][0] = (int)(me[q] & 0xFFFFu), mm[q][5] = (int)(me[q] >> 16);
-                        mm[q][1] = (int)(m02[q] & 0xFFFFu), mm[q][3] = (int)(m02[q] >> 16);
-                        mm[q][2] = (int)(m13[q] & 0xFFFFu), mm[q][4] = (int)(m13[q] >> 16);
-                    }
-                    const int gxs[4] = {(int)(short)(gx02[0] & 0xFFFFu), (int)(short)(gx13[0] & 0xFFFFu), (int)(short)(gx02[0] >> 16),
-                                        (int)(short)(gx13[0] >> 16)};
-                    const int gys[4] = {(int)(short)(gy02[0] & 0xFFFFu), (int)(short)(gy13[0] & 0xFFFFu), (int)(short)(gy02[0] >> 16),
-                                        (int)(short)(gy13[0] >> 16)};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int m = mm[1][k + 1];
-                        const int xs = gxs[k], ysg = gys[k];
-                        const int ax = abs(xs), ay = abs(ysg) << 15;
-                        const int tg22x = __mul24(ax, 13573);                    // |gx| <= 1020
-                        const int tg67x = tg22x + (ax << 16);
-                        const bool neg = (xs ^ ysg) < 0;
-                        // the two neighbours along the gradient, and whether the second comparison is strict
-                        const bool hz = ay < tg22x, vt = ay > tg67x;
-                        const int n1 = hz ? mm[1][k] : (vt ? mm[0][k + 1] : (neg ? mm[0][k + 2] : mm[0][k]));
-                        const int n2 = hz ? mm[1][k + 2] : (vt ? mm[2][k + 1] : (neg ? mm[2][k] : mm[2][k + 2]));
-                        const bool is_max = m > n1 && (m > n2 || ((hz || vt) && m == n2));
-                        const unsigned code = (unsigned)min(m >> 1, 255);
-                        o |= (is_max ? code : 0u) << (8 * k);
+                const unsigned G02 = g0 | (g2 << 16), G13 = g1 | (g3 << 16);
+                // ---- horizontal 1 4 6 4 1 with the neighbours' pixels (reflect-101 at the image's left / right edge) ----
+                const unsigned R21 = hi_lo(G02, G13);                    // (g2, g1): columns -2,-1 and w,w+1 mirror to these
+                unsigned gprev = dpp_prev_u32(hi_hi(G02, G13));          // the previous lane's (g2, g3) = columns x-2, x-1
+                unsigned gnext = dpp_next_u32(lo_lo(G02, G13));          // the next lane's (g0, g1) = columns x+4, x+5
+                gprev = at_left ? R21 : gprev, gnext = at_right ? R21 : gnext;
+                const unsigned L2 = lo_lo(gprev, G02), L1 = hi_lo(gprev, G13);      // (g-2, g0), (g-1, g1)
+                const unsigned R2 = hi_lo(G02, gnext), R3 = hi_hi(G13, gnext);      // (g2, g4), (g3, g5)
+                H02[k] = pk_addu(pk_addu(L2, R2), pk_addu(pk_shlu(pk_addu(L1, G13), 2), pk_mulu(G02, 6)));
+                H13[k] = pk_addu(pk_addu(L1, R3), pk_addu(pk_shlu(pk_addu(G02, R2), 2), pk_mulu(G13, 6)));
+                // ---- vertical: U[r-1], then blurred row b = r-2 -------------------------------------------------
+                U02[k] = pk_addu(pk_addu(H02[k2], H02[k]), pk_shlu(H02[k1], 1));
+                U13[k] = pk_addu(pk_addu(H13[k2], H13[k]), pk_shlu(H13[k1], 1));
+                const unsigned V02 = pk_addu(pk_addu(U02[k2], U02[k]), pk_addu(pk_shlu(U02[k1], 1), 0x00800080u));
+                const unsigned V13 = pk_addu(pk_addu(U13[k2], U13[k]), pk_addu(pk_shlu(U13[k1], 1), 0x00800080u));
+                const unsigned p02 = pk_shru(V02, 8), p13 = pk_shru(V13, 8);        // (o0, o2), (o1, o3)
+                P02[k] = p02, P13[k] = p13;
+                const int bl = r - 2;
+                if (bl >= yb && bl < y_end) {                            // this wave owns the blurred row: histogram (+ debug copy)
+                    if (out_lane) {
+                        const unsigned o0 = p02 & 0xFFFFu, o2 = p02 >> 16, o1 = p13 & 0xFFFFu, o3 = p13 >> 16;
+                        if (KEEP_BLUR) *reinterpret_cast<unsigned*>(blur + fo + (size_t)bl * w + x) = p02 | (p13 << 8);
+                        if (p02 == p13 && o0 == o2) atomicAdd(&hl[o0], 4u);
+                        else atomicAdd(&hl[o0], 1u), atomicAdd(&hl[o1], 1u), atomicAdd(&hl[o2], 1u), atomicAdd(&hl[o3], 1u);
                     }
                 }
-                *reinterpret_cast<unsigned*>(nm + fo + (size_t)yo * w + x) = o;
+                {   // blurred neighbours across the lane border: PE = (column x-1 | column x+4 << 16), replicated at the image edge
+                    unsigned dp = dpp_prev_u32(p13), dn = dpp_next_u32(p02);        // .hi = o3 of the previous lane, .lo = o0 of the next
+                    dp = at_left ? (p02 << 16) : dp, dn = at_right ? (p13 >> 16) : dn;
+                    PE[k] = hi_lo(dp, dn);
+                }
+                // ---- Sobel of row ym = r-3 from blurred rows r-4, r-3, r-2 (replicated at the image's top / bottom) ----
+                const int ym = r - 3;
+                {
+                    unsigned t02 = P02[k2], t13 = P13[k2], te = PE[k2], b02 = P02[k], b13 = P13[k], be = PE[k];
+                    const unsigned c02 = P02[k1], c13 = P13[k1], ce = PE[k1];
+                    if (ym == 0) t02 = c02, t13 = c13, te = ce;
+                    if (ym == h - 1) b02 = c02, b13 = c13, be = ce;
+                    const unsigned v02 = pk_addu(pk_addu(t02, b02), pk_shlu(c02, 1)), v13 = pk_addu(pk_addu(t13, b13), pk_shlu(c13, 1)),
+                                   ve = pk_addu(pk_addu(te, be), pk_shlu(ce, 1));
+                    const unsigned d02 = pk_sub16(b02, t02), d13 = pk_sub16(b13, t13), de = pk_sub16(be, te);
+                    const unsigned dx02 = pk_sub16(v13, lo_lo(ve, v13));                       // V[k+1] - V[k-1] for pixels 0, 2
+                    const unsigned dx13 = pk_sub16(hi_hi(v02, ve), v02);                       //                  for pixels 1, 3
+                    const unsigned dy02 = pk_add16(pk_add16(lo_lo(de, d13), pk_add16(d02, d02)), d13);
+                    const unsigned dy13 = pk_add16(pk_add16(d02, pk_add16(d13, d13)), hi_hi(d02, de));
+                    const unsigned ax02 = pk_abs16(dx02), ax13 = pk_abs16(dx13), ay02 = pk_abs16(dy02), ay13 = pk_abs16(dy13);
+                    const unsigned inm = (ym >= 0 && ym < h) ? lane_mask : 0u;                 // magnitude is 0 outside the image
+                    const unsigned m02 = (ax02 + ay02) & inm, m13 = (ax13 + ay13) & inm;       // <= 2040 per half: plain add
+                    M02[k] = m02, M13[k] = m13;
+                    ME[k] = hi_lo(dpp_prev_u32(m13), dpp_next_u32(m02));                       // (m of column x-1 | m of column x+4 << 16)
+                    // direction class, cv::Canny's fixed-point tests in 16 bits: with t22 = floor(|gx| * 13573 / 2^15)
+                    //   |gy| * 2^15 <  |gx| * 13573           <=>  |gy| <= t22         (|gx| > 0; at |gx| = 0 both sides need |gy| = 0,
+                    //                                                                   where the magnitude is 0 and nothing is a maximum)
+                    //   |gy| * 2^15 >  |gx| * (13573 + 2^16)  <=>  |gy| >  t22 + 2 |gx|
+                    // 13573 = 53 * 256 + 5, so t22 = (53 |gx| + ((5 |gx|) >> 8)) >> 7 without leaving 16 bits (|gx| <= 1020)
+                    const unsigned t02q = pk_shru(pk_addu(pk_mulu(ax02, 53), pk_shru(pk_mulu(ax02, 5), 8)), 7);
+                    const unsigned t13q = pk_shru(pk_addu(pk_mulu(ax13, 53), pk_shru(pk_mulu(ax13, 5), 8)), 7);
+                    HZ02[k] = opaque(pk_sar15(pk_sub16(pk_sub16(ay02, t02q), 0x00010001u)));           // |gy| - t22 - 1 < 0
+                    HZ13[k] = opaque(pk_sar15(pk_sub16(pk_sub16(ay13, t13q), 0x00010001u)));
+                    VT02[k] = opaque(pk_sar15(pk_sub16(pk_addu(t02q, pk_shlu(ax02, 1)), ay02)));        // t22 + 2|gx| - |gy| < 0
+                    VT13[k] = opaque(pk_sar15(pk_sub16(pk_addu(t13q, pk_shlu(ax13, 1)), ay13)));
+                    NG02[k] = opaque(pk_sar15(dx02 ^ dy02)), NG13[k] = opaque(pk_sar15(dx13 ^ dy13));          // gradient signs differ
+                }
+                // ---- NMS of row yo = r-4: magnitude rows r-5 (slot k2), r-4 (k1), r-3 (k); class masks of row r-4 (k1) ----
+                const int yo = r - 4;
+                if (yo >= yb && yo < y_end) {
+                    const unsigned mT02 = M02[k2], mT13 = M13[k2], mTE = ME[k2], mC02 = M02[k1], mC13 = M13[k1], mCE = ME[k1],
+                                   mB02 = M02[k], mB13 = M13[k], mBE = ME[k];
+                    // pixels 0,2: left (m-1, m1), right M13; pixels 1,3: left M02, right (m2, m4); same for the rows above / below
+                    const unsigned l02 = lo_lo(mCE, mC13), r13 = hi_hi(mC02, mCE);
+                    const unsigned ul02 = lo_lo(mTE, mT13), ur13 = hi_hi(mT02, mTE), dl02 = lo_lo(mBE, mB13), dr13 = hi_hi(mB02, mBE);
+                    const unsigned hz02 = HZ02[k1], hz13 = HZ13[k1], vt02 = VT02[k1], vt13 = VT13[k1], ng02 = NG02[k1], ng13 = NG13[k1];
+                    // first neighbour (must be strictly smaller): left | up | up-right (signs differ) | up-left
+                    const unsigned n1a = bsel(hz02, l02, bsel(vt02, mT02, bsel(ng02, mT13, ul02)));
+                    const unsigned n1b = bsel(hz13, mC02, bsel(vt13, mT13, bsel(ng13, ur13, mT02)));
+                    // second neighbour: right | down (these two may be equal) | down-left (signs differ) | down-right
+                    const unsigned n2a = bsel(hz02, mC13, bsel(vt02, mB02, bsel(ng02, dl02, mB13)));
+                    const unsigned n2b = bsel(hz13, r13, bsel(vt13, mB13, bsel(ng13, mB02, dr13)));
+                    // m > n1 and (m >= n2 on the horizontal / vertical classes, m > n2 on the diagonals): m - mask adds 1 where mask = 0xFFFF
+                    const unsigned ea = pk_minu(pk_subsat(mC02, n1a), pk_subsat(pk_sub16(mC02, hz02 | vt02), n2a));
+                    const unsigned eb = pk_minu(pk_subsat(mC13, n1b), pk_subsat(pk_sub16(mC13, hz13 | vt13), n2b));
+                    const unsigned ca = pk_minu(pk_shru(mC02, 1), 0x00FF00FFu);
+                    const unsigned cb = pk_minu(pk_shru(mC13, 1), 0x00FF00FFu);
+                    const unsigned oa = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, ca) * __builtin_bit_cast(u16x2_t, opaque(pk_minu(ea, 0x00010001u))));
+                    const unsigned ob = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, cb) * __builtin_bit_cast(u16x2_t, opaque(pk_minu(eb, 0x00010001u))));
+                    if (out_lane) *reinterpret_cast<unsigned*>(nm + fo + (size_t)yo * w + x) = oa | (ob << 8);
+                }
             }
         }
     }
@@ -913,80 +950,80 @@ __device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4
     out[3] = cand & ~UCm & URm & ~Rm;
 }
 
+// A workgroup takes CT_STACK vertically adjacent tiles, all map chunks loaded up front, the non-empty ones resolved one
+// after the other in the same LDS arrays.  Measured at 720p, 64 frames: one tile per workgroup 37 us, four 53 us --
+// the non-empty tiles (lane markings, vehicle outlines) sit above each other and then run serially -- so CT_STACK = 1.
+constexpr int CT_STACK = 1;
 template <bool NM>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,
                                                        const double* __restrict__ thr, unsigned* __restrict__ labels_all) {
     __shared__ unsigned lab[CT_PX];               // local label: pixel index inside the tile (row * 256 + column), bit 31 = weak
     __shared__ unsigned cm[CT_NCH];               // per 16-pixel chunk: candidate bits | strong bits << 16
-    const int tid = threadIdx.x, x0 = blockIdx.x * CT_C, y0 = blockIdx.y * CT_R, s = blockIdx.z;
+    static_assert(CT_NCH == 256, "one chunk per thread and tile");
+    const int tid = threadIdx.x, x0 = blockIdx.x * CT_C, s = blockIdx.z;
     const uint8_t* m = map_all + (size_t)s * h * w;
     unsigned* glab = labels_all + (size_t)s * h * w;
     int lo2 = 0, hi2 = 0;
     if (NM) half_thresholds(thr, s, lo2, hi2);
-    constexpr int Q = CT_NCH / 256;
-    unsigned candq[Q];
-    bool any = false;
+    const int c = tid, r = c / CT_CH, cc = c % CT_CH;
+    const int x = x0 + cc * 16;
+    uint4 vq[CT_STACK];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
-        const int y = y0 + r, x = x0 + cc * 16;
+    for (int t = 0; t < CT_STACK; ++t) {
+        const int y = ((int)blockIdx.y * CT_STACK + t) * CT_R + r;
         const unsigned none = NM ? 0u : 0x01010101u;
-        uint4 v = make_uint4(none, none, none, none);
-        if (y < h && x < w) v = *reinterpret_cast<const uint4*>(m + (size_t)y * w + x);          // w % 16 == 0
-        unsigned cand, strong;
-        map_bits<NM>(v, lo2, hi2, cand, strong);
-        candq[q] = cand;
-        cm[c] = cand | strong << 16;
-        any = any || cand != 0;
-        // own label, or the smallest label of the horizontal run inside the chunk (first strong pixel, else first pixel)
-        unsigned rest = cand;
-        while (rest) {
-            const int a = __ffs((int)rest) - 1;
-            const unsigned run = rest & ~(rest + (1u << a));
-            rest &= ~run;
-            const unsigned sr = strong & run;
-            const int rp = sr ? __ffs((int)sr) - 1 : a;
-            const unsigned rep = (unsigned)(c * 16 + rp) | (sr ? 0u : 0x80000000u);
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if ((run >> k) & 1u) lab[c * 16 + k] = rep;
-        }
+        vq[t] = make_uint4(none, none, none, none);
+        if (y < h && x < w) vq[t] = *reinterpret_cast<const uint4*>(m + (size_t)y * w + x);      // w % 16 == 0
     }
-    if (__syncthreads_or(any ? 1 : 0) == 0) return;               // no candidate in the tile: the labels are never read
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const unsigned cand = candq[q];
-        if (!cand) continue;
-        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
-        // neighbours outside the tile count as absent here: the border pass makes those links
-        const unsigned Lb = cc > 0 ? (cm[c - 1] >> 15) & 1u : 0u, Rb = cc < CT_CH - 1 ? cm[c + 1] & 1u : 0u;
-        unsigned ucand = 0, ULb = 0, URb = 0;
-        if (r > 0) {
-            ucand = cm[c - CT_CH] & 0xFFFFu;
-            ULb = cc > 0 ? (cm[c - CT_CH - 1] >> 15) & 1u : 0u;
-            URb = cc < CT_CH - 1 ? cm[c - CT_CH + 1] & 1u : 0u;
-        }
-        unsigned link[4];
-        ccl_links((cand << 1) | Lb | (Rb << 17), (ucand << 1) | ULb | (URb << 17), link);
+    for (int t = 0; t < CT_STACK; ++t) {
+        const int y0 = ((int)blockIdx.y * CT_STACK + t) * CT_R;
+        if (y0 >= h) break;
+        unsigned cand, strong;
+        map_bits<NM>(vq[t], lo2, hi2, cand, strong);
+        if (__syncthreads_or(cand != 0 ? 1 : 0) == 0) continue;       // no candidate in the tile (also fences the previous tile's reads)
+        cm[c] = cand | strong << 16;
+        {   // own label, or the smallest label of the horizontal run inside the chunk (first strong pixel, else first pixel)
+            unsigned rest = cand;
+            while (rest) {
+                const int a = __ffs((int)rest) - 1;
+                const unsigned run = rest & ~(rest + (1u << a));
+                rest &= ~run;
+                const unsigned sr = strong & run;
+                const int rp = sr ? __ffs((int)sr) - 1 : a;
+                const unsigned rep = (unsigned)(c * 16 + rp) | (sr ? 0u : 0x80000000u);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            unsigned bits = link[t];
-            while (bits) {
-                const int k = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                const unsigned me = (unsigned)(c * 16 + k);
-                lds_union(lab, me, t == 0 ? me - 1u : me - (unsigned)CT_C + (unsigned)t - 2u);
+                for (int k = 0; k < 16; ++k)
+                    if ((run >> k) & 1u) lab[c * 16 + k] = rep;
             }
         }
-    }
-    __syncthreads();
-    // every candidate -> the global label of its tile-local root
+        __syncthreads();
+        if (cand) {
+            // neighbours outside the tile count as absent here: the border pass makes those links
+            const unsigned Lb = cc > 0 ? (cm[c - 1] >> 15) & 1u : 0u, Rb = cc < CT_CH - 1 ? cm[c + 1] & 1u : 0u;
+            unsigned ucand = 0, ULb = 0, URb = 0;
+            if (r > 0) {
+                ucand = cm[c - CT_CH] & 0xFFFFu;
+                ULb = cc > 0 ? (cm[c - CT_CH - 1] >> 15) & 1u : 0u;
+                URb = cc < CT_CH - 1 ? cm[c - CT_CH + 1] & 1u : 0u;
+            }
+            unsigned link[4];
+            ccl_links((cand << 1) | Lb | (Rb << 17), (ucand << 1) | ULb | (URb << 17), link);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        unsigned bits = candq[q];
-        if (!bits) continue;
-        const int c = tid + q * 256, r = c / CT_CH, cc = c % CT_CH;
-        unsigned* out = glab + (size_t)(y0 + r) * w + x0 + cc * 16;
+            for (int q = 0; q < 4; ++q) {
+                unsigned bits = link[q];
+                while (bits) {
+                    const int k = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    const unsigned me = (unsigned)(c * 16 + k);
+                    lds_union(lab, me, q == 0 ? me - 1u : me - (unsigned)CT_C + (unsigned)q - 2u);
+                }
+            }
+        }
+        __syncthreads();
+        // every candidate -> the global label of its tile-local root
+        unsigned bits = cand;
+        unsigned* out = glab + (size_t)(y0 + r) * w + x;
         while (bits) {
             const int k = __ffs((int)bits) - 1;
             bits &= bits - 1;
@@ -1037,7 +1074,7 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restri
 // Only the box of chunks [bx0, bx0 + bcw) x [by0, by0 + bch) is visited: the whole frame when the pre-ROI edge map is
 // wanted or the ROI is caller-defined, else the bounding box of the default trapezoid -- outside it the masked map
 // is never written by anybody (it is zero since av_lane_workspace_init and the Hough stage only erases).
-constexpr int FCK = 4;
+constexpr int FCK = 1;        // one chunk per thread: a thread's component look-ups are a dependent chain, more of them per thread only lengthens it
 template <bool NM>
 __global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__ map_all, int h, int w,
                                                      const double* __restrict__ thr, unsigned* __restrict__ labels_all, Roi roi,
@@ -1134,6 +1171,84 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict_
         const int tot = red[0] + red[1] + red[2] + red[3];
         if (on) out[base + off + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned)x | ((unsigned)y << 16);
         base += tot;
+    }
+}
+
+// The same list for the chunk box the resolve pass visited (w % 16 == 0): a few workgroups per frame, each scans the
+// box's per-row counts in LDS (redundantly), then their waves share the rows of the box, a lane per 16-pixel chunk: non-zero bytes ->
+// bit mask -> wave prefix of the pop-counts -> the points, row-major.  (The per-row kernel above starts one workgroup
+// per image row, each summing all the counts before it: 46 080 workgroups and 30 us per 64 frames at 720p.)
+constexpr int CB_ROWS = 8192;                   // rows the scan holds (the box is 288 rows for the default ROI at 720p)
+__global__ void __launch_bounds__(1024) compact_box_kernel(const uint8_t* __restrict__ masked, int h, int w,
+                                                           const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
+                                                           int* __restrict__ npts, int bx0, int by0, int bcw, int bch) {
+    extern __shared__ int cb_base[];                        // [bch] exclusive prefix of the box rows' counts
+    __shared__ int wtot[16];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gw = (int)blockIdx.y * 16 + wid, nw = (int)gridDim.y * 16;      // this wave among the frame's waves (every workgroup repeats the scan)
+    const int* rc = rowcnt + (size_t)s * h + by0;
+    const int per = (bch + 1023) / 1024;                    // consecutive rows per thread (<= 8)
+    int loc[8], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = tid * per + q;
+        loc[q] = (q < per && i < bch) ? rc[i] : 0;
+        sum += loc[q];
+    }
+    // exclusive scan of the 1024 per-thread sums: inside each wave by shuffles, then over the 16 wave totals
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += v;
+    }
+    if (lane == 63) wtot[wid] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wid; ++q) woff += wtot[q];
+    int run = woff + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = tid * per + q;
+        if (q < per && i < bch) cb_base[i] = run;
+        run += loc[q];
+    }
+    if (tid == 1023 && blockIdx.y == 0) npts[s] = run;       // thread 1023's running total = all points of the frame
+    __syncthreads();
+    unsigned* out = nz + (size_t)s * h * w;
+    for (int i = gw; i < bch; i += nw) {
+        if (rc[i] == 0) continue;                           // wave-uniform
+        const int y = by0 + i;
+        int base = cb_base[i];
+        const uint8_t* row = masked + ((size_t)s * h + y) * w + (size_t)bx0 * 16;
+        uint4 vnext = make_uint4(0, 0, 0, 0);
+        if (lane < bcw) vnext = *reinterpret_cast<const uint4*>(row + (size_t)lane * 16);
+        for (int c0 = 0; c0 < bcw; c0 += 64) {
+            const int c = c0 + lane;
+            const uint4 v = vnext;
+            vnext = make_uint4(0, 0, 0, 0);
+            if (c + 64 < bcw) vnext = *reinterpret_cast<const uint4*>(row + (size_t)(c + 64) * 16);      // next trip in flight
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) bits |= (b[k] != 0 ? 1u : 0u) << k;
+            const int n = __popc(bits);
+            int pre = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(pre, d, 64);
+                if (lane >= d) pre += t;
+            }
+            const int tot = __shfl(pre, 63, 64);
+            int o = base + pre - n;
+            const unsigned xb = (unsigned)((bx0 + c) * 16);
+            while (bits) {
+                const int k = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                out[o++] = (xb + (unsigned)k) | ((unsigned)y << 16);
+            }
+            base += tot;
+        }
     }
 }
 
@@ -2229,9 +2344,14 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         // other shapes take the two-pass kernels with the blurred image in memory between them
         const bool fused = streamp && fastp && !getenv("AVHOT_LANE_TWO_PASS");
         if (fused) {
-            const dim3 fgrid((((w + SW - 1) / SW) * ((h + FROWS - 1) / FROWS) + 3) / 4, 1, n_streams);     // waves = strips x bands
-            if (stages & 1) hipLaunchKernelGGL(front_stream<true>, fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
-            else hipLaunchKernelGGL(front_stream<false>, fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            const char* fe = getenv("AVHOT_LANE_FROWS");
+            const int fr = fe ? atoi(fe) : 45;                       // measured at 720p, 64 frames: 45 rows 122 us, 72 rows 128, 90 rows 123
+            const int frows = (stages & 1) ? 72 : (fr == 72 ? 72 : (fr == 90 ? 90 : 45));
+            const dim3 fgrid((((w + SW - 1) / SW) * ((h + frows - 1) / frows) + 3) / 4, 1, n_streams);     // waves = strips x bands
+            if (stages & 1) hipLaunchKernelGGL((front_stream<true, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else if (frows == 45) hipLaunchKernelGGL((front_stream<false, 45>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else if (frows == 90) hipLaunchKernelGGL((front_stream<false, 90>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else hipLaunchKernelGGL((front_stream<false, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             AV_LAUNCH_CHECK();
             hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
             AV_LAUNCH_CHECK();
@@ -2251,8 +2371,9 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         Roi roi;
         roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
         roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
+        int cbox[4] = {0, 0, w >> 4, h}, cbox_rows = h;               // chunk box of the resolve / compaction passes
         if (fastp) {
-            const dim3 tgrid((w + CT_C - 1) / CT_C, (h + CT_R - 1) / CT_R, n_streams);
+            const dim3 tgrid((w + CT_C - 1) / CT_C, ((h + CT_R - 1) / CT_R + CT_STACK - 1) / CT_STACK, n_streams);
             if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
             else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
             const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
@@ -2269,6 +2390,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                 by0 = roi.yt < h ? roi.yt : h - 1, bch = h - by0;
                 bx0 = roi.x0 >> 4, bcw = (((roi.x3 < w ? roi.x3 : w - 1) >> 4) - bx0) + 1;
             }
+            cbox[0] = bx0, cbox[1] = by0, cbox[2] = bcw, cbox[3] = bch, cbox_rows = bch;
             const unsigned fchunks = (unsigned)bch * (unsigned)bcw;
             const dim3 ngrid((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams);
             if (fused)
@@ -2284,7 +2406,10 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                                roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
         }
         AV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
+        if (fastp && cbox_rows <= CB_ROWS)
+            hipLaunchKernelGGL(compact_box_kernel, dim3(n_streams, 4), dim3(1024), (size_t)cbox_rows * sizeof(int), st, masked, h, w,
+                               rowcnt, nz, npts, cbox[0], cbox[1], cbox[2], cbox[3]);
+        else hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
         AV_LAUNCH_CHECK();
     }
     if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)

@@ -256,11 +256,13 @@ class PerceptionLoop:
         for cin, cout, k, s, _ in conv_specs():
             sizes.append((cin, cout, k, s))
         self.flops_per_frame = _yolo_flops(net_h, net_w)
-        # algorithmic HBM bytes per pixel of the lane pixel stages (bench.py): read BGR 3, write + read the blurred image 2,
-        # write the edge map 1; the Hough stage's read of the edge map is the 7th byte of SURVEY 8d's 7*W*H
-        self.lane_pixel_bytes_per_px = 6
-        self.lane_pixel_kernels = ("gray_blur_hist_stream + thresholds + sobel_nms_stream + ccl_tile + ccl_border + "
-                                   "finalize_fast + compact")
+        # HBM bytes per pixel the lane pixel stages have to move (bench.py): read BGR 3, write the non-maximum-suppressed
+        # magnitudes 1, read them for the hysteresis pass 1 (the resolve / compaction passes only touch the ROI box: +0.3).
+        # SURVEY 8d's 7*W*H per frame assumed the blurred image goes out to memory and back; the fused front end keeps it
+        # in registers, so the chain as a whole is priced on 7*W*H and this stage on what it really needs
+        self.lane_pixel_bytes_per_px = 5
+        self.lane_pixel_kernels = ("front_stream (gray+blur+hist+Sobel+NMS) + thresholds + ccl_tile + ccl_border + "
+                                   "finalize_fast + compact_box")
         self.frame_idx = 0
         self._lanes_pending = False
         self.stream.synchronize()

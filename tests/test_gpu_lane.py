@@ -18,9 +18,20 @@ def _frames():
     from oracle.lane_ref import synthetic_frame
     rng = np.random.RandomState(5)
     noise = rng.randint(0, 256, size=(96, 200, 3)).astype(np.uint8)
+    # the fused streaming front end takes widths that are multiples of 16: noise exercises every gradient-direction class
+    # and tie rule of the non-maximum suppression, two strips wide (496 > 248 columns) and two row bands (150 > 72 rows);
+    # "bright" has a median above 196 (hi saturates at 255, lo/hi halving at its limit), "dark" a median of 1 (lo = 0)
+    noise16 = rng.randint(0, 256, size=(150, 496, 3)).astype(np.uint8)
+    bright = rng.randint(190, 256, size=(80, 256, 3)).astype(np.uint8)
+    bright[20:40, 50:90] = 0
+    bright[50:70, 150:230] = rng.randint(0, 60, size=(20, 80, 3))
+    dark = (rng.randint(0, 10, size=(72, 64, 3)) // 4).astype(np.uint8)
+    steps = (np.arange(96)[:, None] // 7 * 37 + np.arange(320)[None, :] // 5 * 53) % 256          # plateaus: equal neighbours
+    steps = np.repeat(steps[:, :, None], 3, axis=2).astype(np.uint8)
     return [("synthetic720", synthetic_frame(720, 1280, 0, 0)), ("synthetic480", synthetic_frame(480, 640, 3, 7)),
             ("odd_size", synthetic_frame(250, 333, 1, 2)), ("noise", noise),
-            ("flat", np.full((64, 80, 3), 90, np.uint8))]
+            ("flat", np.full((64, 80, 3), 90, np.uint8)), ("noise16", noise16), ("bright", bright), ("dark", dark),
+            ("steps", steps)]
 
 
 @pytest.mark.parametrize("name,frame", _frames(), ids=[n for n, _ in _frames()])
