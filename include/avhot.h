@@ -76,6 +76,14 @@ int av_event_record(void* ev, av_stream_t stream);
 int av_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int av_stream_sync(av_stream_t stream);
 
+/* Pinned host staging buffers and stream-ordered copies for the per-frame class surfaces (one packed upload and
+ * one packed download per detect() / update() / step() / plan() call; demo.py:107-120 calls them once per frame).
+ * av_copy_d2h with sync != 0 also waits for the stream, i.e. for the results. */
+int av_host_alloc(void** p, size_t bytes);
+int av_host_free(void* p);
+int av_copy_h2d(void* dst_dev, const void* src_host, size_t bytes, av_stream_t stream);
+int av_copy_d2h(void* dst_host, const void* src_dev, size_t bytes, av_stream_t stream, int sync);
+
 /* ---- D1: simulated detector -------------------------------------------------------------------
  * Replaces ObjectDetector.detect -> _detect_simulated (src/perception/detector.py:86-101,125-169).
  * Detections are a pure function of (frame_count, h, w): the reference reseeds NumPy's legacy

@@ -35,3 +35,69 @@ class Dev:
 
     def sync(self):
         torch.cuda.current_stream(self.device).synchronize()
+
+
+class Packed:
+    """One device buffer and one pinned host mirror carved into the same named, typed fields.
+
+    The per-frame class surfaces (one frame per call, results read on the host after every call) pay for every
+    separate copy and allocation; with this, a call is: write the inputs into the host views, ONE upload, the kernel,
+    ONE download (+ stream sync), read the host views.  fields: [(name, numpy dtype, shape)], each 64-byte aligned.
+    `h[name]` is a NumPy view of the pinned host copy, `ptr(name)` the device address of the field."""
+
+    def __init__(self, dev, fields):
+        import ctypes as C
+        self._dev, self._lib = dev, dev.lib
+        off, self._off, self._shape, self._dtype = 0, {}, {}, {}
+        for name, dt, shape in fields:
+            dt = np.dtype(dt)
+            n = int(np.prod(shape)) * dt.itemsize
+            self._off[name], self._shape[name], self._dtype[name] = off, tuple(shape), dt
+            off += (n + 63) & ~63
+        self.nbytes = max(off, 64)
+        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev.device)
+        self._base = self.dev.data_ptr()
+        hp = C.c_void_p()
+        nat.check(self._lib.av_host_alloc(C.byref(hp), self.nbytes))
+        self._hp = hp
+        raw = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(hp.value))
+        raw[:] = 0
+        self._raw = raw
+        self.h = {}
+        for name in self._off:
+            o, dt, sh = self._off[name], self._dtype[name], self._shape[name]
+            self.h[name] = raw[o:o + int(np.prod(sh)) * dt.itemsize].view(dt).reshape(sh)
+
+    def ptr(self, name):
+        import ctypes as C
+        return C.c_void_p(self._base + self._off[name])
+
+    def tensor(self, name, torch_dtype):
+        """Device tensor view of a field."""
+        o, sh = self._off[name], self._shape[name]
+        n = int(np.prod(sh)) * self._dtype[name].itemsize
+        return self.dev[o:o + n].view(torch_dtype).view(*sh)
+
+    def upload(self, upto=None):
+        """Host -> device, the whole buffer or the leading fields up to and including `upto`."""
+        n = self.nbytes
+        if upto is not None:
+            n = self._off[upto] + ((int(np.prod(self._shape[upto])) * self._dtype[upto].itemsize + 63) & ~63)
+        nat.check(self._lib.av_copy_h2d(self._base, self._hp, n, self._dev.stream))
+
+    def download(self, first=None, sync=True):
+        """Device -> host (from field `first` to the end), then wait for the stream."""
+        o = self._off[first] if first is not None else 0
+        nat.check(self._lib.av_copy_d2h(self._hp.value + o, self._base + o, self.nbytes - o, self._dev.stream, 1 if sync else 0))
+
+    def close(self):
+        if getattr(self, "_hp", None) is not None and self._hp:
+            self.h, self._raw = {}, None
+            self._lib.av_host_free(self._hp)
+            self._hp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

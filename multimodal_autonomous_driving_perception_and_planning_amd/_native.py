@@ -81,6 +81,10 @@ _SIGS = [
     ("av_event_record", C.c_int, [vp, vp]),
     ("av_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     ("av_stream_sync", C.c_int, [vp]),
+    ("av_host_alloc", C.c_int, [C.POINTER(vp), C.c_size_t]),
+    ("av_host_free", C.c_int, [vp]),
+    ("av_copy_h2d", C.c_int, [vp, vp, C.c_size_t, vp]),
+    ("av_copy_d2h", C.c_int, [vp, vp, C.c_size_t, vp, C.c_int]),
     ("av_simdet_generate", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     ("av_tracker_state_bytes", C.c_size_t, [C.c_int, C.c_int]),
     ("av_tracker_reset", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),

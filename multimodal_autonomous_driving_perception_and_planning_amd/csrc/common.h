@@ -19,8 +19,9 @@ struct av_ctx {
     av_planner_cfg pcfg{};
     int n_points = 0, n_lat = 0, n_cand = 0;
     double* d_ptab = nullptr;          // device: t[n] | alpha[n] | q[n] | dtdiff[n] | lat[n_lat]
-    // simulated detector: class cdf (8 doubles)
+    // simulated detector: class cdf (8 doubles); the draws of the 1000 possible per-frame seeds (simdet.hip)
     double* d_cdf = nullptr;
+    void* d_simtab = nullptr;
     std::vector<hipGraphExec_t> graphs;
     // lane / yolo sub-contexts are attached by their own translation units
     void* lane = nullptr;

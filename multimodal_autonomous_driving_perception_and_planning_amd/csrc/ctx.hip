@@ -5,6 +5,8 @@
 
 static thread_local char g_err[512] = "no error";
 
+int av_simdet_ctx_init(av_ctx* ctx);        // simdet.hip: builds the per-seed draw table
+
 void av_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -64,6 +66,8 @@ int av_ctx_create(int device, av_ctx** out) {
     for (int i = 0; i < 8; ++i) cdf[i] = cdf[i] / last;
     AV_HIP(hipMalloc(&c->d_cdf, sizeof(cdf)));
     AV_HIP(hipMemcpy(c->d_cdf, cdf, sizeof(cdf), hipMemcpyHostToDevice));
+    const int rc = av_simdet_ctx_init(c);
+    if (rc != AV_OK) return rc;
     *out = c;
     return AV_OK;
 }
@@ -82,6 +86,7 @@ int av_ctx_destroy(av_ctx* ctx) {
     av_yolo_ctx_free(ctx);
     if (ctx->d_ptab) (void)hipFree(ctx->d_ptab);
     if (ctx->d_cdf) (void)hipFree(ctx->d_cdf);
+    if (ctx->d_simtab) (void)hipFree(ctx->d_simtab);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -178,6 +183,28 @@ int av_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 int av_stream_sync(av_stream_t stream) {
     AV_HIP(hipStreamSynchronize(as_stream(stream)));
+    return AV_OK;
+}
+
+// Pinned host staging for the per-frame class surfaces: one packed upload and one packed download per call.
+int av_host_alloc(void** p, size_t bytes) {
+    AV_REQUIRE(p && bytes > 0, AV_EINVAL, "av_host_alloc: null out pointer or zero size");
+    AV_HIP(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return AV_OK;
+}
+int av_host_free(void* p) {
+    if (p) AV_HIP(hipHostFree(p));
+    return AV_OK;
+}
+int av_copy_h2d(void* dst_dev, const void* src_host, size_t bytes, av_stream_t stream) {
+    AV_REQUIRE(dst_dev && src_host, AV_EINVAL, "av_copy_h2d: null pointer");
+    AV_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return AV_OK;
+}
+int av_copy_d2h(void* dst_host, const void* src_dev, size_t bytes, av_stream_t stream, int sync) {
+    AV_REQUIRE(dst_host && src_dev, AV_EINVAL, "av_copy_d2h: null pointer");
+    AV_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    if (sync) AV_HIP(hipStreamSynchronize(as_stream(stream)));
     return AV_OK;
 }
 

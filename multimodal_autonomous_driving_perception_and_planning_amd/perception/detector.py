@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .._dev import Dev
+from .._dev import Dev, Packed
 
 
 @dataclass
@@ -45,13 +45,12 @@ class ObjectDetector:
         self.model = None
         self.frame_count = 0
         self._dev = Dev(device)
-        d = self._dev
-        self._fc = d.zeros(1, torch.int32)
-        self._n = d.zeros((1, 1), torch.int32)
-        self._box = d.zeros((1, 1, self.DCAP, 4), torch.int32)
-        self._cls = d.zeros((1, 1, self.DCAP), torch.int32)
-        self._conf = d.zeros((1, 1, self.DCAP), torch.float64)
-        self._status = d.zeros(1, torch.int32)
+        # one device buffer + pinned host mirror: counter (uploaded only when the host's frame_count was changed behind
+        # the device's back), then the outputs, fetched with one copy per frame
+        self._io = Packed(self._dev, [("fc", np.int32, (1,)), ("n", np.int32, (1, 1)), ("box", np.int32, (1, 1, self.DCAP, 4)),
+                                      ("cls", np.int32, (1, 1, self.DCAP)), ("conf", np.float64, (1, 1, self.DCAP)),
+                                      ("status", np.int32, (1,))])
+        self._dev_fc = None                      # what the device counter holds (None: unknown)
         if mode == "yolo" and model_path:
             self._load_yolo_model(model_path)
 
@@ -77,17 +76,19 @@ class ObjectDetector:
 
     def _detect_simulated(self, frame) -> List[Detection]:
         h, w = frame.shape[:2]
-        d = self._dev
-        self._fc.fill_(self.frame_count - 1)        # kernel generates frame_count = counter + 1
-        nat.check(d.lib.av_simdet_generate(d.ctx.handle, d.stream, 1, 1, int(h), int(w), self.DCAP,
-                                           nat.ptr(self._fc), nat.ptr(self._n), nat.ptr(self._box),
-                                           nat.ptr(self._cls), nat.ptr(self._conf), nat.ptr(self._status)))
-        n = int(self._n.item())
-        box = self._box.cpu().numpy()[0, 0]
-        cls = self._cls.cpu().numpy()[0, 0]
-        conf = self._conf.cpu().numpy()[0, 0]
-        return [Detection(bbox=tuple(int(v) for v in box[i]), class_id=int(cls[i]),
-                          class_name=self.CLASSES[int(cls[i])], confidence=float(conf[i])) for i in range(n)]
+        d, io = self._dev, self._io
+        if self._dev_fc != self.frame_count - 1:    # the kernel generates frame counter + 1 and advances the counter
+            io.h["fc"][0] = self.frame_count - 1
+            io.upload(upto="fc")
+        nat.check(d.lib.av_simdet_generate(d.ctx.handle, d.stream, 1, 1, int(h), int(w), self.DCAP, io.ptr("fc"), io.ptr("n"),
+                                           io.ptr("box"), io.ptr("cls"), io.ptr("conf"), io.ptr("status")))
+        io.download(first="n")
+        self._dev_fc = self.frame_count
+        n = int(io.h["n"][0, 0])
+        box, cls, conf = io.h["box"][0, 0, :n].tolist(), io.h["cls"][0, 0, :n].tolist(), io.h["conf"][0, 0, :n].tolist()
+        names = self.CLASSES
+        return [Detection(bbox=tuple(box[i]), class_id=cls[i], class_name=names[cls[i]], confidence=conf[i])
+                for i in range(n)]
 
     def draw_detections(self, frame: np.ndarray, detections: List[Detection], show_labels: bool = True,
                         show_confidence: bool = True) -> np.ndarray:

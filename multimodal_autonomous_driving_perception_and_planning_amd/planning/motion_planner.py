@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .._dev import Dev
+from .._dev import Dev, Packed
 
 
 @dataclass
@@ -131,7 +131,12 @@ class MotionPlanner:
             nat.check(d.lib.av_planner_dims(d.ctx.handle, C.byref(n), C.byref(c)))
             self._n, self._c = n.value, c.value
             self._sig = sig
+            # start state up, every candidate's waypoints + costs + ranking down: one copy each way per plan()
+            self._io = Packed(d, [("st", np.float64, (1, 4)), ("wp", np.float64, (1, self._c, self._n, nat.WP_DOUBLES)),
+                                  ("cost", np.float64, (1, self._c)), ("order", np.int32, (1, self._c))])
             self._lat = np.linspace(-3.5, 3.5, int(self.num_samples))
+            self._kinds = ["lane_keep" if abs(self._lat[c // 3]) < 0.5 else
+                           ("lane_change_left" if self._lat[c // 3] < 0 else "lane_change_right") for c in range(self._c)]
 
     def _ref_arrays(self):
         if not self.reference_trajectory:
@@ -195,21 +200,19 @@ class MotionPlanner:
              obstacles: Optional[List[Tuple[float, float, float]]] = None) -> Tuple[Trajectory, List[Trajectory]]:
         self._configure()
         d = self._dev
-        st = d.upload(np.asarray(current_state, np.float64).reshape(1, 4), np.float64)
+        io = self._io
+        io.h["st"][0] = np.asarray(current_state, np.float64).reshape(4)
+        io.upload(upto="st")
         ref, nr = self._ref_arrays()
         obs, no = self._obs_arrays(d, obstacles)
-        wp = d.empty((1, self._c, self._n, nat.WP_DOUBLES), torch.float64)
-        cost = d.empty((1, self._c), torch.float64)
-        order = d.empty((1, self._c), torch.int32)
-        nat.check(d.lib.av_planner_plan(d.ctx.handle, d.stream, 1, nat.ptr(st), nat.ptr(ref), nr, nat.ptr(obs), no,
-                                        nat.ptr(wp), nat.ptr(cost), nat.ptr(order)))
-        wph, costh, orderh = wp.cpu().numpy()[0], cost.cpu().numpy()[0], order.cpu().numpy()[0]
-        gen = []
-        for c in range(self._c):
-            lat = self._lat[c // 3]
-            kind = "lane_keep" if abs(lat) < 0.5 else ("lane_change_left" if lat < 0 else "lane_change_right")
-            gen.append(Trajectory._from_array(wph[c], cost=float(costh[c]), trajectory_type=kind))
-        candidates = [gen[int(c)] for c in orderh]
+        nat.check(d.lib.av_planner_plan(d.ctx.handle, d.stream, 1, io.ptr("st"), nat.ptr(ref), nr, nat.ptr(obs), no,
+                                        io.ptr("wp"), io.ptr("cost"), io.ptr("order")))
+        io.download(first="wp")
+        wph = io.h["wp"][0].copy()                 # the staging buffer is reused by the next call
+        costh, orderh = io.h["cost"][0].tolist(), io.h["order"][0].tolist()
+        kinds = self._kinds
+        gen = [Trajectory._from_array(wph[c], cost=costh[c], trajectory_type=kinds[c]) for c in range(self._c)]
+        candidates = [gen[c] for c in orderh]
         return (candidates[0] if candidates else None), candidates
 
     def draw_trajectories(self, frame: np.ndarray, optimal: Optional[Trajectory], candidates: List[Trajectory],

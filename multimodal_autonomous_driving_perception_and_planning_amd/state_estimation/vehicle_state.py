@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .._dev import Dev
+from .._dev import Dev, Packed
 
 
 @dataclass
@@ -95,9 +95,8 @@ class VehicleStateEstimator:
         self._dev = Dev(device)
         d = self._dev
         self._state = d.zeros((1, nat.KF_STATE_DOUBLES), torch.float64)
-        self._z = d.zeros((1, 1, 4), torch.float64)
-        self._mode = d.zeros((1, 1), torch.uint8)
-        self._out = d.zeros((1, 1, nat.VSTATE_DOUBLES), torch.float64)
+        # measurement + mode go up in one copy, the derived state comes back in one
+        self._io = Packed(d, [("z", np.float64, (1, 1, 4)), ("mode", np.uint8, (1, 1)), ("out", np.float64, (1, 1, nat.VSTATE_DOUBLES))])
         self.kf = _FilterView(self)
         self.state_history: List[VehicleState] = []
         self.reset()
@@ -109,13 +108,15 @@ class VehicleStateEstimator:
             zz = np.asarray(z, np.float64).reshape(-1)
             if zz.size != 4:
                 raise ValueError("measurement must have 4 elements [x, y, vx, vy], got shape %s" % (np.shape(z),))
-            self._z.copy_(torch.as_tensor(zz).view(1, 1, 4))
-        self._mode.fill_(mode)
+            self._io.h["z"][0, 0] = zz
+        io = self._io
+        io.h["mode"][0, 0] = mode
+        io.upload(upto="mode")
         cfg = nat.KfCfg(float(self.dt), float(self._q), float(self._r))
-        nat.check(d.lib.av_kf_step(d.ctx.handle, d.stream, C.byref(cfg), 1, 1, nat.ptr(self._z), nat.ptr(self._mode),
-                                   nat.ptr(self._state), nat.ptr(self._out), None))
-        v = self._out.cpu().numpy()[0, 0]
-        return VehicleState(*[float(t) for t in v[:11]])
+        nat.check(d.lib.av_kf_step(d.ctx.handle, d.stream, C.byref(cfg), 1, 1, io.ptr("z"), io.ptr("mode"),
+                                   nat.ptr(self._state), io.ptr("out"), None))
+        io.download(first="out")
+        return VehicleState(*io.h["out"][0, 0, :11].tolist())
 
     @property
     def time(self):

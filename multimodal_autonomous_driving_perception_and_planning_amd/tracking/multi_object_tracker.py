@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .._dev import Dev
+from .._dev import Dev, Packed
 
 _ROW = np.dtype(nat.TRACK_ROW_FIELDS)
 
@@ -73,13 +73,11 @@ class MultiObjectTracker:
         self._tcap, self._dcap, self._L = tcap, dcap, int(self.trajectory_length)
         self._bytes = int(d.lib.av_tracker_state_bytes(tcap, self._L))
         self._state = d.zeros((1, self._bytes), torch.uint8)
-        self._snap = d.zeros((1, 1, tcap, nat.TRACK_ROW_BYTES), torch.uint8)
-        self._snap_n = d.zeros((1, 1), torch.int32)
-        self._d2t = d.zeros((1, 1, dcap), torch.int32)
-        self._dn = d.zeros((1, 1), torch.int32)
-        self._dbox = d.zeros((1, 1, dcap, 4), torch.int32)
-        self._dcls = d.zeros((1, 1, dcap), torch.int32)
-        self._dconf = d.zeros((1, 1, dcap), torch.float64)
+        # the frame's detections go up in one copy; the table after the frame (rows carry bbox, counters, history length
+        # and the last velocity) comes back in one -- the 100-KB state with the history rings stays on the device
+        self._io = Packed(d, [("dn", np.int32, (1, 1)), ("dbox", np.int32, (1, 1, dcap, 4)), ("dcls", np.int32, (1, 1, dcap)),
+                              ("dconf", np.float64, (1, 1, dcap)), ("snap_n", np.int32, (1, 1)),
+                              ("snap", np.uint8, (1, 1, tcap, nat.TRACK_ROW_BYTES)), ("d2t", np.int32, (1, 1, dcap))])
 
     def _reset_device(self):
         d = self._dev
@@ -132,63 +130,79 @@ class MultiObjectTracker:
         n = len(detections)
         if len(self.tracks) + n > self._tcap or n > self._dcap:
             self._grow(len(self.tracks) + n, n)
-        box = np.zeros((self._dcap, 4), np.int32)
-        cls = np.zeros(self._dcap, np.int32)
-        conf = np.zeros(self._dcap, np.float64)
+        io = self._io
+        box, cls, conf = io.h["dbox"][0, 0], io.h["dcls"][0, 0], io.h["dconf"][0, 0]
+        names = self._names
         for j, det in enumerate(detections):
             box[j] = det.bbox
             cls[j] = det.class_id
             conf[j] = det.confidence
-            self._names.setdefault(int(det.class_id), det.class_name)
-        self._dn.fill_(n)
-        self._dbox.copy_(torch.as_tensor(box).view(1, 1, self._dcap, 4))
-        self._dcls.copy_(torch.as_tensor(cls).view(1, 1, self._dcap))
-        self._dconf.copy_(torch.as_tensor(conf).view(1, 1, self._dcap))
+            if det.class_id not in names:
+                names[int(det.class_id)] = det.class_name
+        box[n:] = 0
+        io.h["dn"][0, 0] = n
+        io.upload(upto="dconf")
         cfg = self._cfg()
-        nat.check(d.lib.av_tracker_update(d.ctx.handle, d.stream, C.byref(cfg), 1, 1, self._dcap, nat.ptr(self._dn),
-                                          nat.ptr(self._dbox), nat.ptr(self._dcls), nat.ptr(self._dconf), self._tcap,
-                                          nat.ptr(self._state), nat.ptr(self._snap), nat.ptr(self._snap_n),
-                                          nat.ptr(self._d2t)))
-        self._mirror(detections)
-        return [t for t in self.tracks.values() if t.hits >= self.min_hits]
+        nat.check(d.lib.av_tracker_update(d.ctx.handle, d.stream, C.byref(cfg), 1, 1, self._dcap, io.ptr("dn"), io.ptr("dbox"),
+                                          io.ptr("dcls"), io.ptr("dconf"), self._tcap, nat.ptr(self._state), io.ptr("snap"),
+                                          io.ptr("snap_n"), io.ptr("d2t")))
+        io.download(first="snap_n")
+        self._mirror()
+        mh = self.min_hits
+        return [t for t in self.tracks.values() if t.hits >= mh]
 
-    def _mirror(self, detections):
-        """Bring the Python Track objects in line with the device table (the table is the truth)."""
-        hdr, rows, hist = self._host_state()
-        if hdr[3] != 0:
-            raise RuntimeError("track table overflow on device (status=%d)" % hdr[3])
-        n = int(hdr[0])
-        self.next_id, self.frame_count = int(hdr[1]), int(hdr[2])
+    def _mirror(self):
+        """Bring the Python Track objects in line with the device table (the table is the truth).  One frame at a
+        time a track gains at most one history entry -- its new centre and, unless it was just born, the centre
+        difference the row carries as its last velocity -- so the rings are only fetched when that does not hold."""
+        io = self._io
+        n = int(io.h["snap_n"][0, 0])
+        if n > self._tcap:
+            raise RuntimeError("track table overflow on device (%d rows, capacity %d)" % (n, self._tcap))
+        rows = io.h["snap"][0, 0].view(_ROW).reshape(self._tcap)[:n]
+        self.frame_count += 1
         L = self._L
-        by_name = {}
-        for det in detections:
-            by_name.setdefault(int(det.class_id), det.class_name)
-        new = {}
+        ids, x1, y1, x2, y2 = rows["id"].tolist(), rows["x1"].tolist(), rows["y1"].tolist(), rows["x2"].tolist(), rows["y2"].tolist()
+        cls, age, hits, misses = rows["cls"].tolist(), rows["age"].tolist(), rows["hits"].tolist(), rows["misses"].tolist()
+        hls, conf, vx, vy = rows["hist_len"].tolist(), rows["conf"].tolist(), rows["vx"].tolist(), rows["vy"].tolist()
+        old, new, hist = self.tracks, {}, None
         for k in range(n):
-            r = rows[k]
-            tid = int(r["id"])
-            t = self.tracks.get(tid)
-            hl, slot = int(r["hist_len"]), int(r["slot"])
+            tid = ids[k]
+            t = old.get(tid)
+            hl = hls[k]
             if t is None:
-                cid = int(r["cls"])
-                t = Track(track_id=tid, bbox=(0, 0, 0, 0), class_id=cid,
-                          class_name=by_name.get(cid, self._names.get(cid, str(cid))), confidence=0.0)
+                cid = cls[k]
+                t = Track(track_id=tid, bbox=(0, 0, 0, 0), class_id=cid, class_name=self._names.get(cid, str(cid)), confidence=0.0)
                 t._hist_len = 0
-            t.bbox = (int(r["x1"]), int(r["y1"]), int(r["x2"]), int(r["y2"]))
-            t.confidence = float(r["conf"])
-            t.age, t.hits, t.misses = int(r["age"]), int(r["hits"]), int(r["misses"])
-            if hl != t._hist_len:                      # new ring entries since the last mirror
+            t.bbox = (x1[k], y1[k], x2[k], y2[k])
+            t.confidence = conf[k]
+            t.age, t.hits, t.misses = age[k], hits[k], misses[k]
+            gap = hl - t._hist_len
+            if gap == 1:                               # matched or born in this frame
+                t.trajectory.append(((x1[k] + x2[k]) / 2, (y1[k] + y2[k]) / 2))
+                if hl > 1:
+                    t.velocities.append((vx[k], vy[k]))
+                if len(t.trajectory) > L:
+                    del t.trajectory[:-L]
+                    del t.velocities[:-L]
+                t._hist_len = hl
+            elif gap != 0:                             # not reachable one frame at a time: rebuild from the device rings
+                if hist is None:
+                    hist = self._host_state()[2]
+                slot = int(rows["slot"][k])
                 for e in range(max(t._hist_len, hl - L), hl):
-                    cx, cy, vx, vy = hist[slot, e % L]
+                    cx, cy, ex, ey = hist[slot, e % L]
                     t.trajectory.append((float(cx), float(cy)))
                     if e > 0:
-                        t.velocities.append((float(vx), float(vy)))
+                        t.velocities.append((float(ex), float(ey)))
                 if len(t.trajectory) > L:
                     t.trajectory = t.trajectory[-L:]
                     t.velocities = t.velocities[-L:]
                 t._hist_len = hl
             new[tid] = t
         self.tracks = new
+        if n:
+            self.next_id = max(self.next_id, ids[-1] + 1)       # rows are in ascending id order; ids are never re-used
 
     def get_all_trajectories(self) -> Dict[int, List[Tuple[float, float]]]:
         return {tid: t.trajectory.copy() for tid, t in self.tracks.items() if t.hits >= self.min_hits}
