@@ -75,6 +75,7 @@ int av_event_destroy(void* ev);
 int av_event_record(void* ev, av_stream_t stream);
 int av_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int av_stream_sync(av_stream_t stream);
+int av_stream_sync_spin(av_stream_t stream);                   /* the same, polling (no interrupt wake-up latency) */
 
 /* Pinned host staging buffers and stream-ordered copies for the per-frame class surfaces (one packed upload and
  * one packed download per detect() / update() / step() / plan() call; demo.py:107-120 calls them once per frame).

@@ -45,9 +45,13 @@ class Packed:
     ONE download (+ stream sync), read the host views.  fields: [(name, numpy dtype, shape)], each 64-byte aligned.
     `h[name]` is a NumPy view of the pinned host copy, `ptr(name)` the device address of the field."""
 
-    def __init__(self, dev, fields):
+    def __init__(self, dev, fields, mapped=True):
+        """mapped=True: no device copy at all -- kernels read the inputs from and write the results to the pinned host
+        buffer itself (hipHostMalloc memory is mapped into the device's address space; a few hundred bytes to a few
+        KB per call cross PCIe inside the kernel instead of as two extra copy commands, each ~8 us of host time);
+        upload() is then a no-op and download() only waits for the stream."""
         import ctypes as C
-        self._dev, self._lib = dev, dev.lib
+        self._dev, self._lib, self.mapped = dev, dev.lib, mapped
         off, self._off, self._shape, self._dtype = 0, {}, {}, {}
         for name, dt, shape in fields:
             dt = np.dtype(dt)
@@ -55,11 +59,14 @@ class Packed:
             self._off[name], self._shape[name], self._dtype[name] = off, tuple(shape), dt
             off += (n + 63) & ~63
         self.nbytes = max(off, 64)
-        self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev.device)
-        self._base = self.dev.data_ptr()
         hp = C.c_void_p()
         nat.check(self._lib.av_host_alloc(C.byref(hp), self.nbytes))
         self._hp = hp
+        if mapped:
+            self.dev, self._base = None, hp.value
+        else:
+            self.dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev.device)
+            self._base = self.dev.data_ptr()
         raw = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(hp.value))
         raw[:] = 0
         self._raw = raw
@@ -73,13 +80,17 @@ class Packed:
         return C.c_void_p(self._base + self._off[name])
 
     def tensor(self, name, torch_dtype):
-        """Device tensor view of a field."""
+        """Device tensor view of a field (copy mode only)."""
+        if self.mapped:
+            raise RuntimeError("a mapped Packed buffer has no device tensor")
         o, sh = self._off[name], self._shape[name]
         n = int(np.prod(sh)) * self._dtype[name].itemsize
         return self.dev[o:o + n].view(torch_dtype).view(*sh)
 
     def upload(self, upto=None):
         """Host -> device, the whole buffer or the leading fields up to and including `upto`."""
+        if self.mapped:
+            return
         n = self.nbytes
         if upto is not None:
             n = self._off[upto] + ((int(np.prod(self._shape[upto])) * self._dtype[upto].itemsize + 63) & ~63)
@@ -87,6 +98,10 @@ class Packed:
 
     def download(self, first=None, sync=True):
         """Device -> host (from field `first` to the end), then wait for the stream."""
+        if self.mapped:
+            if sync:
+                nat.check(self._lib.av_stream_sync_spin(self._dev.stream))
+            return
         o = self._off[first] if first is not None else 0
         nat.check(self._lib.av_copy_d2h(self._hp.value + o, self._base + o, self.nbytes - o, self._dev.stream, 1 if sync else 0))
 

@@ -81,6 +81,7 @@ _SIGS = [
     ("av_event_record", C.c_int, [vp, vp]),
     ("av_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     ("av_stream_sync", C.c_int, [vp]),
+    ("av_stream_sync_spin", C.c_int, [vp]),
     ("av_host_alloc", C.c_int, [C.POINTER(vp), C.c_size_t]),
     ("av_host_free", C.c_int, [vp]),
     ("av_copy_h2d", C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -186,6 +186,23 @@ int av_stream_sync(av_stream_t stream) {
     return AV_OK;
 }
 
+// Waits for the stream by polling an event instead of sleeping on the completion interrupt: a per-frame call waits for
+// ~10 us of work, and the interrupt path's wake-up latency is of that order.
+int av_stream_sync_spin(av_stream_t stream) {
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) AV_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    AV_HIP(hipEventRecord(ev, as_stream(stream)));
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return AV_OK;
+        if (e != hipErrorNotReady) {
+            av_set_error("av_stream_sync_spin: hipEventQuery -> %s", hipGetErrorString(e));
+            return AV_EHIP;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 // Pinned host staging for the per-frame class surfaces: one packed upload and one packed download per call.
 int av_host_alloc(void** p, size_t bytes) {
     AV_REQUIRE(p && bytes > 0, AV_EINVAL, "av_host_alloc: null out pointer or zero size");

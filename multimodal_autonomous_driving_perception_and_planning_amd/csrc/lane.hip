@@ -2140,42 +2140,48 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
 }
 
 // ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
-__device__ void jacobi3(double A[3][3], double V[3][3]) {        // symmetric eigen-decomposition, A -> diag
+// one Jacobi rotation in the (P, Q) plane; P, Q compile-time so that A and V stay in registers (run-time indices put them
+// in scratch memory, which made this 3x3 problem a 40-us kernel)
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rot(double (&A)[3][3], double (&V)[3][3]) {
+    if (fabs(A[P][Q]) < 1e-300) return;
+    const double th = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);
+    const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double akp = A[k][P], akq = A[k][Q];
+        A[k][P] = c * akp - sn * akq, A[k][Q] = sn * akp + c * akq;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double apk = A[P][k], aqk = A[Q][k];
+        A[P][k] = c * apk - sn * aqk, A[Q][k] = sn * apk + c * aqk;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double vkp = V[k][P], vkq = V[k][Q];
+        V[k][P] = c * vkp - sn * vkq, V[k][Q] = sn * vkp + c * vkq;
+    }
+}
+__device__ __forceinline__ void jacobi3(double (&A)[3][3], double (&V)[3][3]) {        // symmetric eigen-decomposition, A -> diag
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) V[r][c] = r == c ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
         const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
         if (off < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (fabs(A[p][q]) < 1e-300) continue;
-                const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq, A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk, A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq, V[k][q] = sn * vkp + c * vkq;
-                }
-            }
+        jacobi_rot<0, 1>(A, V);
+        jacobi_rot<0, 2>(A, V);
+        jacobi_rot<1, 2>(A, V);
     }
 }
 
-// one thread per (stream, side)
-__global__ void lane_fit_kernel(int S, int h, int w, int max_segments, double smoothing, const int* __restrict__ segs,
-                                const int* __restrict__ nseg, double* __restrict__ lane_state,
-                                double* __restrict__ poly, int* __restrict__ pts, int* __restrict__ info,
-                                double* __restrict__ conf, const double* __restrict__ thr, const int* __restrict__ npts) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= S * 2) return;
-    const int s = id >> 1, side = id & 1;
+__device__ void lane_fit_one(int s, int side, int h, int w, int max_segments, double smoothing, const int* __restrict__ segs,
+                             const int* __restrict__ nseg, double* __restrict__ lane_state, double* __restrict__ poly,
+                             int* __restrict__ info, double* __restrict__ conf, const double* __restrict__ thr,
+                             const int* __restrict__ npts, double* coef) {
     const int n = nseg[s];
     const int* sg = segs + (size_t)s * max_segments * 4;
     const double cx = (double)w / 2.0;
@@ -2236,16 +2242,31 @@ __global__ void lane_fit_kernel(int S, int h, int w, int max_segments, double sm
     st[0] = c2, st[1] = c1, st[2] = c0, st[3] = 1.0;
     double* po = poly + ((size_t)s * 2 + side) * 3;
     po[0] = c2, po[1] = c1, po[2] = c0;
-    // np.linspace(h*0.6, h, 50); np.polyval (Horner); astype(int32) truncates toward zero
-    const double ya = (double)h * 0.6, yb = (double)h, step = (yb - ya) / 49.0;
-    int* pp = pts + ((size_t)s * 2 + side) * 100;
-    for (int k = 0; k < 50; ++k) {
-        const double y = k == 49 ? yb : (double)k * step + ya;
-        const double x = (c2 * y + c1) * y + c0;
-        pp[2 * k] = (int)x, pp[2 * k + 1] = (int)y;
-    }
+    coef[0] = c2, coef[1] = c1, coef[2] = c0, coef[3] = 1.0;
     inf[side] = 1;
     conf[(size_t)s * 2 + side] = fmin(1.0, (double)nl / 10.0);          // :172
+}
+
+// one wave per (stream, side): lane 0 does the fit, then lane k makes point k of the 50
+__global__ void __launch_bounds__(64) lane_fit_kernel(int S, int h, int w, int max_segments, double smoothing, const int* __restrict__ segs,
+                                const int* __restrict__ nseg, double* __restrict__ lane_state,
+                                double* __restrict__ poly, int* __restrict__ pts, int* __restrict__ info,
+                                double* __restrict__ conf, const double* __restrict__ thr, const int* __restrict__ npts) {
+    const int id = blockIdx.x, lane = threadIdx.x;
+    if (id >= S * 2) return;
+    const int s = id >> 1, side = id & 1;
+    __shared__ double coef[4];                                           // c2 c1 c0 valid
+    if (lane == 0) coef[3] = 0.0;
+    if (lane == 0) lane_fit_one(s, side, h, w, max_segments, smoothing, segs, nseg, lane_state, poly, info, conf, thr, npts, coef);
+    __syncthreads();
+    if (coef[3] == 0.0 || lane >= 50) return;
+    // np.linspace(h*0.6, h, 50); np.polyval (Horner); astype(int32) truncates toward zero
+    const double c2 = coef[0], c1 = coef[1], c0 = coef[2];
+    const double ya = (double)h * 0.6, yb = (double)h, step = (yb - ya) / 49.0;
+    int* pp = pts + ((size_t)s * 2 + side) * 100;
+    const double y = lane == 49 ? yb : (double)lane * step + ya;
+    const double x = (c2 * y + c1) * y + c0;
+    pp[2 * lane] = (int)x, pp[2 * lane + 1] = (int)y;
 }
 
 struct LaneCtx {
@@ -2346,11 +2367,13 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         if (fused) {
             const char* fe = getenv("AVHOT_LANE_FROWS");
             const int fr = fe ? atoi(fe) : 45;                       // measured at 720p, 64 frames: 45 rows 122 us, 72 rows 128, 90 rows 123
-            const int frows = (stages & 1) ? 72 : (fr == 72 ? 72 : (fr == 90 ? 90 : 45));
+            // a few frames per launch (the per-frame class calls): short bands, so that a frame is hundreds of waves instead of 96
+            const int frows = (stages & 1) ? 72 : (fe ? (fr == 72 ? 72 : (fr == 90 ? 90 : (fr == 15 ? 15 : 45))) : (n_streams <= 8 ? 15 : 45));
             const dim3 fgrid((((w + SW - 1) / SW) * ((h + frows - 1) / frows) + 3) / 4, 1, n_streams);     // waves = strips x bands
             if (stages & 1) hipLaunchKernelGGL((front_stream<true, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else if (frows == 45) hipLaunchKernelGGL((front_stream<false, 45>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else if (frows == 90) hipLaunchKernelGGL((front_stream<false, 90>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else if (frows == 15) hipLaunchKernelGGL((front_stream<false, 15>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else hipLaunchKernelGGL((front_stream<false, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             AV_LAUNCH_CHECK();
             hipLaunchKernelGGL(thresholds_kernel, dim3(n_streams), dim3(256), 0, st, h, w, hist, thr, rowcnt, npts, nseg);
@@ -2436,7 +2459,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
                        lc->d_trig, segs, nseg, use_fast ? fb : nullptr);
     AV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lane_fit_kernel, dim3((n_streams * 2 + 63) / 64), dim3(64), 0, st, n_streams, h, w,
+    hipLaunchKernelGGL(lane_fit_kernel, dim3(n_streams * 2), dim3(64), 0, st, n_streams, h, w,
                        cfg->max_segments, cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);
     AV_LAUNCH_CHECK();
     return AV_OK;

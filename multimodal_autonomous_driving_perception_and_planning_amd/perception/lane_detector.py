@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from .._dev import Dev
+from .._dev import Dev, Packed
 
 
 @dataclass
@@ -55,29 +55,26 @@ class LaneDetector:
         self.smoothing_factor = 0.7
         self._dev = Dev(device)
         d = self._dev
-        self._state = d.zeros((1, 8), torch.float64)
-        self._poly = d.zeros((1, 2, 3), torch.float64)
-        self._pts = d.zeros((1, 2, 50, 2), torch.int32)
-        self._info = d.zeros((1, 8), torch.int32)
-        self._conf = d.zeros((1, 2), torch.float64)
+        # EMA record and every result live in one host-mapped buffer: the fit kernel reads / writes it in place
+        self._io = Packed(d, [("state", np.float64, (1, 8)), ("poly", np.float64, (1, 2, 3)), ("pts", np.int32, (1, 2, 50, 2)),
+                              ("info", np.int32, (1, 8)), ("conf", np.float64, (1, 2))])
         self._shape = None
         self._ws = None
         self._roi = None
-        self._frame = None
+        self._stage = None
 
     # prev_*_fit mirror the device record so user code that reads or clears them keeps working
     def _get_fit(self, side):
-        rec = self._state.cpu().numpy()[0, side * 4:side * 4 + 4]
+        rec = self._io.h["state"][0, side * 4:side * 4 + 4]
         return rec[:3].copy() if rec[3] != 0.0 else None
 
     def _set_fit(self, side, value):
-        rec = self._state.cpu().numpy()[0]
+        rec = self._io.h["state"][0]
         if value is None:
             rec[side * 4:side * 4 + 4] = 0.0
         else:
             rec[side * 4:side * 4 + 3] = np.asarray(value, np.float64).reshape(3)
             rec[side * 4 + 3] = 1.0
-        self._state.copy_(torch.as_tensor(rec).view(1, 8))
 
     prev_left_fit = property(lambda self: self._get_fit(0), lambda self, v: self._set_fit(0, v))
     prev_right_fit = property(lambda self: self._get_fit(1), lambda self, v: self._set_fit(1, v))
@@ -89,7 +86,7 @@ class LaneDetector:
         nbytes = int(d.lib.av_lane_workspace_bytes(1, h, w, self.MAX_SEGMENTS))
         self._ws = d.empty(nbytes, torch.uint8)
         nat.check(d.lib.av_lane_workspace_init(d.ctx.handle, d.stream, 1, h, w, self.MAX_SEGMENTS, nat.ptr(self._ws)))
-        self._frame = d.empty((1, h, w, 3), torch.uint8)
+        self._stage = Packed(d, [("frame", np.uint8, (1, h, w, 3))], mapped=False)      # pinned staging for the frame upload
         self._roi = None
         if self.roi_vertices is not None:
             self._roi = d.upload(_roi_rows(self.roi_vertices, h, w), np.int32)
@@ -109,18 +106,19 @@ class LaneDetector:
         h, w = frame.shape[:2]
         self._prepare(h, w)
         d = self._dev
-        self._frame.copy_(torch.as_tensor(frame).view(1, h, w, 3))
+        np.copyto(self._stage.h["frame"][0], frame)
+        self._stage.upload()
+        io = self._io
         cfg = nat.LaneCfg(50, 50, 150, self.MAX_SEGMENTS, float(self.smoothing_factor))
-        nat.check(d.lib.av_lane_detect(d.ctx.handle, d.stream, C.byref(cfg), 1, h, w, nat.ptr(self._frame),
-                                       nat.ptr(self._roi), nat.ptr(self._ws), nat.ptr(self._state), nat.ptr(self._poly),
-                                       nat.ptr(self._pts), nat.ptr(self._info), nat.ptr(self._conf), stages))
+        nat.check(d.lib.av_lane_detect(d.ctx.handle, d.stream, C.byref(cfg), 1, h, w, self._stage.ptr("frame"),
+                                       nat.ptr(self._roi), nat.ptr(self._ws), io.ptr("state"), io.ptr("poly"),
+                                       io.ptr("pts"), io.ptr("info"), io.ptr("conf"), stages))
+        io.download()
 
     def detect(self, frame: np.ndarray) -> Tuple[Optional[LaneLine], Optional[LaneLine]]:
         self._run(frame)
-        info = self._info.cpu().numpy()[0]
-        poly = self._poly.cpu().numpy()[0]
-        pts = self._pts.cpu().numpy()[0]
-        conf = self._conf.cpu().numpy()[0]
+        h = self._io.h
+        info, poly, pts, conf = h["info"][0], h["poly"][0], h["pts"][0], h["conf"][0]
         out = []
         for side, name in ((0, "left"), (1, "right")):
             if info[side]:
@@ -152,4 +150,4 @@ class LaneDetector:
         return frame_width / 2 - lane_center
 
     def reset(self):
-        self._state.zero_()
+        self._io.h["state"][:] = 0.0

@@ -1,26 +1,43 @@
 #!/usr/bin/env python3
-"""Per-stage host+device time of the per-frame drop-in classes (the demo.py-style loop, one frame per call)."""
-import sys, time, numpy as np
-import os
+"""Per-stage host+device time of the per-frame drop-in classes (the demo.py-style loop, one frame per call):
+mean, median and 95th percentile per stage over 300 frames."""
+import argparse, os, sys, time
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion, synthetic_frame
 from src.perception import ObjectDetector, LaneDetector
 from src.tracking import MultiObjectTracker
 from src.state_estimation import VehicleStateEstimator
 from src.planning import MotionPlanner
+ap = argparse.ArgumentParser()
+ap.add_argument("--no-lanes", action="store_true")
+ap.add_argument("--json", action="store_true")
+a = ap.parse_args()
 det, lane, trk, est, pl = ObjectDetector(mode="simulated"), LaneDetector(), MultiObjectTracker(), VehicleStateEstimator(), MotionPlanner()
 ego = generate_ego_motion(320)
 frames = [synthetic_frame(720, 1280, 0, f) for f in range(8)]
-T = dict(detect=0, lane=0, track=0, kf=0, plan=0)
+names = ("detect", "lane", "track", "kf", "plan")
+T = {k: [] for k in names}
 for i in range(320):
     fr = frames[i % 8]
     t0 = time.perf_counter(); d = det.detect(fr)
-    t1 = time.perf_counter(); l, r = lane.detect(fr)
+    t1 = time.perf_counter()
+    if not a.no_lanes: l, r = lane.detect(fr)
     t2 = time.perf_counter(); tr = trk.update(d)
     t3 = time.perf_counter(); st = est.step(np.array(ego[i]))
     t4 = time.perf_counter(); opt, cands = pl.plan((st.x, st.y, st.heading, st.speed))
     t5 = time.perf_counter()
     if i >= 20:
-        for k, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)): T[k] += v
-for k, v in T.items(): print("%-7s %.3f ms/frame" % (k, v / 300 * 1e3))
-print("total   %.3f ms/frame" % (sum(T.values()) / 300 * 1e3))
+        for k, v in zip(names, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)): T[k].append(v * 1e3)
+out = {}
+for k in names:
+    v = np.array(T[k])
+    out[k] = dict(mean=round(float(v.mean()), 4), median=round(float(np.median(v)), 4), p95=round(float(np.percentile(v, 95)), 4))
+    if not a.json: print("%-7s mean %.3f  median %.3f  p95 %.3f ms/frame" % (k, out[k]["mean"], out[k]["median"], out[k]["p95"]))
+tot = sum(np.array(T[k]) for k in names)
+out["total"] = dict(mean=round(float(tot.mean()), 4), median=round(float(np.median(tot)), 4), p95=round(float(np.percentile(tot, 95)), 4))
+if a.json:
+    import json
+    print(json.dumps(out))
+else:
+    print("total   mean %.3f  median %.3f  p95 %.3f ms/frame" % (out["total"]["mean"], out["total"]["median"], out["total"]["p95"]))
