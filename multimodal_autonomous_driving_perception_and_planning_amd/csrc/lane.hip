@@ -1445,7 +1445,12 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
-    if (check_flag && fallback[s] == 0) return;                 // already done by houghp_shard
+    // the flag is both this kernel's input (1: houghp_shard gave the frame up) and its verdict for houghp_kernel, written
+    // by thread 0 below: every thread must branch on the value read BEFORE that write, so it goes through LDS
+    __shared__ int sh_skip;
+    if (tid == 0) sh_skip = (check_flag && fallback[s] == 0) ? 1 : 0;
+    __syncthreads();
+    if (sh_skip) return;                                        // already done by houghp_shard
     const int total = npts[s];
     const int ymin = total > 0 ? (int)(nzg[0] >> 16) : 0, ymax = total > 0 ? (int)(nzg[total - 1] >> 16) : 0;
     const int wpr = (w + 31) >> 5;

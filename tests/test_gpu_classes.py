@@ -185,3 +185,16 @@ def test_demo_style_loop_matches_cpu_oracle(api):
         assert len(tracks) == int((want["ahm"][f][:want["n_live"][f], 1] >= 3).sum())
         assert st.speed == pytest.approx(want["state"][f][5], rel=1e-9)
         assert opt.cost == pytest.approx(np.min(want["cost"][f]), rel=1e-9)
+
+
+def test_harness_self_test_and_300_frame_loop(capsys):
+    """BASELINE config 1's plumbing run: the `--test` checks the reference's README advertises (README.md:169-187; its
+    demo.py has no such flag) and the 300-frame loop over the five drop-in classes on synthetic 1280x720 input."""
+    from multimodal_autonomous_driving_perception_and_planning_amd import harness
+    assert harness.main(["--test"]) is None
+    out = capsys.readouterr().out
+    for k in range(1, 7):
+        assert "[Test %d]" % k in out, out
+    assert "300-frame loop" in out and "FPS" in out
+    fps = harness.run_loop(60, verbose=False)
+    assert fps > 200.0, fps                      # the reference's own loop manages ~30 frames/s on these stages (BASELINE.md)
