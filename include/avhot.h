@@ -355,6 +355,62 @@ int av_interaction_detect(av_ctx* ctx, av_stream_t stream, const av_interaction_
                           const uint8_t* has_state, const double* vy, void* state, av_interaction_row* rows,
                           av_interaction_summary* summary);
 
+/* ---- rendering ----------------------------------------------------------------
+ * Replaces the cv2 drawing behind BEVRenderer.render (src/visualization/bev_renderer.py:286-348 and its helpers
+ * :92-284,350-364), OverlayRenderer (src/visualization/overlays.py:26-210) and the draw_* methods of the four hot-path
+ * classes (detector.py:171, lane_detector.py:220, multi_object_tracker.py:251, motion_planner.py:305).  A picture is an
+ * ORDERED list of primitives (later ones paint over earlier ones), rasterised per pixel by exact integer tests -- the
+ * geometry of the reference's calls, not OpenCV's scan conversion, labels in a 5x7 bitmap font: parity unpinned
+ * (OpenCV absent), bit-exact against oracle/raster_ref.py. */
+enum {
+    AV_PRIM_RECT = 1,        /* filled, corners (x0,y0)-(x1,y1) inclusive                                   */
+    AV_PRIM_SEG = 2,         /* segment (x0,y0)-(x1,y1), thickness p: pixels within p/2 of it               */
+    AV_PRIM_QUAD = 3,        /* filled convex quadrilateral (x0,y0) (x1,y1) (x2,y2) (x3,y3), edges included */
+    AV_PRIM_DISC = 4,        /* filled circle, centre (x0,y0), radius p                                     */
+    AV_PRIM_RING = 5,        /* circle outline of thickness 1, centre (x0,y0), radius p                     */
+    AV_PRIM_GLYPH = 6,       /* character p (ASCII 32..126) of the 5x7 font, top-left (x0,y0), scale x1     */
+    AV_PRIM_BLEND_RECT = 7,  /* rectangle blended 0.7 picture + 0.3 colour (cv2.addWeighted panels)         */
+    AV_PRIM_POLY_BLEND = 8   /* polygon verts[x0 .. x0+y0), even-odd, blended the same; (x2,y2)-(x3,y3) = its bounding box */
+};
+typedef struct {
+    int32_t type;
+    int32_t x0, y0, x1, y1, x2, y2, x3, y3;
+    int32_t p;
+    uint8_t b, g, r, a;      /* colour in OpenCV's channel order; a unused */
+    int32_t reserved;
+} av_prim;                   /* 48 bytes */
+/*   img     u8 [n_images][h][w][3], drawn in place
+ *   prims   av_prim [n_images][prim_cap], n_prims int32 [n_images]
+ *   verts   int32 [n_images][vert_cap][2] polygon vertices (x, y); may be NULL when no POLY primitive is used */
+int av_raster_draw(av_ctx* ctx, av_stream_t stream, int n_images, int h, int w, uint8_t* img, const av_prim* prims, int prim_cap,
+                   const int32_t* n_prims, const int32_t* verts, int vert_cap);
+/* The BEV panel of BEVRenderer.render (bev_renderer.py:286-348) as a primitive list built ON THE DEVICE from the hot
+ * loop's tables -- planner waypoints + stable order, tracker snapshot rows + history rings, Kalman output -- for frame
+ * `frame` of the window of every stream; paint it with av_raster_draw over the road image.  Layering as the reference:
+ * candidates of rank 1 .. n_candidates-1 (grey), the planned path (rank 0, green, a disc on every third waypoint), the
+ * confirmed tracks (footprint, outline, heading arrow, "ID:n", trail), the ego vehicle + uncertainty circle, the legend.
+ * The list has a fixed layout of av_bev_prim_cap() slots per stream; unused slots are type 0. */
+typedef struct {
+    int32_t width, height;          /* 600, 600 (bev_renderer.py:29-33) */
+    double pixels_per_meter;        /* 10.0 */
+    double x_min, x_max, y_min, y_max;   /* (-30, 30), (-10, 50) */
+    int32_t n_candidates;           /* how many of the ranked candidates to show (demo.py:143 passes candidate_trajs[:10]) */
+    int32_t reserved;
+} av_bev_cfg;
+int av_bev_prim_cap(const av_bev_cfg* cfg, int tcap, int n_points);
+/*   snap, snap_n   [S][W][tcap], [S][W] of av_tracker_update; tracker_state its persistent state (history rings)
+ *   vstate         [S][W][AV_VSTATE_DOUBLES] of av_kf_step, or NULL (no ego vehicle)
+ *   waypoints      [S*W][C][n][6], order [S*W][C] of av_planner_plan
+ *   prims          av_prim [S][prim_cap], n_prims int32 [S]
+ * The history rings hold the trails as of the END of the window: build panels for frame = W-1 (or run W = 1). */
+int av_bev_build(av_ctx* ctx, av_stream_t stream, const av_bev_cfg* cfg, int n_streams, int n_frames, int frame, int tcap,
+                 int trajectory_length, const av_track_row* snap, const int32_t* snap_n, const void* tracker_state,
+                 const double* vstate, const double* waypoints, const int32_t* order, av_prim* prims, int prim_cap, int32_t* n_prims);
+/* Bilinear resize (half-pixel centres) of src [sh][sw][3] into the dh x dw window at column dst_x0 of a picture whose
+ * rows hold dst_pitch_px pixels: OverlayRenderer.create_side_by_side's cv2.resize + hstack (overlays.py:187-196). */
+int av_resize_into(av_ctx* ctx, av_stream_t stream, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, int dst_pitch_px,
+                   int dst_x0);
+
 /* ---- synthetic input ---------------------------------------------------
  * Deterministic 8-bit BGR road scenes generated on the device, standing in for the reference's lost
  * SyntheticDataGenerator (data/generators, source absent).  Frame (stream0+s, frame) is bit-identical to

@@ -56,8 +56,18 @@ INTERACTION_SUMMARY_FIELDS = [("agent_count", "<i4"), ("pedestrian_count", "<i4"
 INTERACTION_SUMMARY_BYTES = 56
 
 
+class BevCfg(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("pixels_per_meter", C.c_double), ("x_min", C.c_double),
+                ("x_max", C.c_double), ("y_min", C.c_double), ("y_max", C.c_double), ("n_candidates", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class InteractionCfg(C.Structure):
     _fields_ = [("frame_h", C.c_int32), ("frame_w", C.c_int32), ("class_kind", C.c_int32 * 16)]
+PRIM_FIELDS = [("type", "<i4"), ("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"),
+               ("x3", "<i4"), ("y3", "<i4"), ("p", "<i4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"), ("reserved", "<i4")]
+PRIM_BYTES = 48
+PRIM_RECT, PRIM_SEG, PRIM_QUAD, PRIM_DISC, PRIM_RING, PRIM_GLYPH, PRIM_BLEND_RECT, PRIM_POLY_BLEND = 1, 2, 3, 4, 5, 6, 7, 8
 VSTATE_DOUBLES = 12
 WP_DOUBLES = 6
 
@@ -104,6 +114,10 @@ _SIGS = [
     ("av_lane_workspace_init", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_lane_workspace_view", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_size_t)]),
+    ("av_raster_draw", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]),
+    ("av_bev_prim_cap", C.c_int, [vp, C.c_int, C.c_int]),
+    ("av_bev_build", C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+    ("av_resize_into", C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("av_synth_frames", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_maneuver_reset", C.c_int, [vp, vp, C.c_int, vp]),
     ("av_interaction_state_bytes", C.c_size_t, [C.c_int]),

@@ -104,7 +104,10 @@ def self_test():
     opt, cands = MotionPlanner().plan((st.x, st.y, st.heading, st.speed))
     assert len(cands) == 21 and len(opt.waypoints) == 51
     print("[Test 5] Motion Planner ... %d candidates, best cost %.2f  ✓" % (len(cands), opt.cost))
-    print("[Test 6] BEV Renderer ... skipped (display code is outside the hot path; see DESIGN.md section 8)")
+    from .visualization import BEVRenderer
+    panel = BEVRenderer().render(ego_state=st, tracks=tracks, planned_trajectory=opt, candidate_trajectories=cands[:10])
+    assert panel.shape == (600, 600, 3) and (panel == (0, 255, 0)).all(axis=2).any()
+    print("[Test 6] BEV Renderer ... %dx%d panel rendered on the device  \u2713" % (panel.shape[1], panel.shape[0]))
     fps = run_loop(300, verbose=False)
     print("300-frame loop (1280x720, simulated detection + lane + track + KF + plan, per-frame class API): %.1f FPS" % fps)
 

@@ -92,19 +92,19 @@ class ObjectDetector:
 
     def draw_detections(self, frame: np.ndarray, detections: List[Detection], show_labels: bool = True,
                         show_confidence: bool = True) -> np.ndarray:
-        """Boxes + labels drawn with OpenCV (display only, not on the hot path)."""
-        import cv2
-        out = frame.copy()
+        """Boxes + labels (detector.py:171-222), drawn by the device rasteriser (visualization/_prims.py)."""
+        from ..visualization._prims import PrimList, paint
+        pl = PrimList()
         for det in detections:
             x1, y1, x2, y2 = det.bbox
             color = self.CLASS_COLORS.get(det.class_id, (255, 255, 255))
-            cv2.rectangle(out, (x1, y1), (x2, y2), color, 2)
+            pl.rectangle((x1, y1), (x2, y2), color, 2)
             if show_labels:
                 text = det.class_name + (" %.2f" % det.confidence if show_confidence else "")
-                (tw, th), _ = cv2.getTextSize(text, cv2.FONT_HERSHEY_SIMPLEX, 0.5, 1)
-                cv2.rectangle(out, (x1, y1 - th - 10), (x1 + tw + 5, y1), color, -1)
-                cv2.putText(out, text, (x1 + 2, y1 - 5), cv2.FONT_HERSHEY_SIMPLEX, 0.5, (0, 0, 0), 1)
-        return out
+                tw, th = 6 * len(text), 9                          # extent of the label in the 5x7 font
+                pl.rectangle((x1, y1 - th - 10), (x1 + tw + 5, y1), color, -1)
+                pl.put_text(text, (x1 + 2, y1 - 5), 0.5, (0, 0, 0), 1)
+        return paint(frame, pl, self._dev.index)
 
     def reset(self):
         self.frame_count = 0

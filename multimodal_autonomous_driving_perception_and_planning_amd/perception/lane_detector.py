@@ -130,17 +130,16 @@ class LaneDetector:
 
     def draw_lanes(self, frame: np.ndarray, left_lane: Optional[LaneLine], right_lane: Optional[LaneLine],
                    fill_lane: bool = True) -> np.ndarray:
-        """Lane overlay (display only, not on the hot path)."""
-        import cv2
+        """Lane area + the two fitted lines (lane_detector.py:220-251), drawn by the device rasteriser."""
+        from ..visualization._prims import PrimList, paint
+        pl = PrimList()
         if fill_lane and left_lane is not None and right_lane is not None:
-            overlay = frame.copy()
-            cv2.fillPoly(overlay, [np.vstack([left_lane.points, right_lane.points[::-1]])], (0, 255, 100))
-            frame = cv2.addWeighted(frame, 0.7, overlay, 0.3, 0)
+            pl.blend_polygon(np.vstack([left_lane.points, right_lane.points[::-1]]), (0, 255, 100))
         if left_lane is not None:
-            cv2.polylines(frame, [left_lane.points], False, (255, 0, 0), 3)
+            pl.polylines(left_lane.points, False, (255, 0, 0), 3)
         if right_lane is not None:
-            cv2.polylines(frame, [right_lane.points], False, (0, 0, 255), 3)
-        return frame
+            pl.polylines(right_lane.points, False, (0, 0, 255), 3)
+        return paint(frame, pl, self._dev.index)
 
     def get_lane_center_offset(self, frame_width: int, left_lane: Optional[LaneLine],
                                right_lane: Optional[LaneLine]) -> Optional[float]:

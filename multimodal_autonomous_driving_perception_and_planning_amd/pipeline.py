@@ -141,6 +141,34 @@ class HotLoop:
                                                nat.ptr(self.snap), nat.ptr(self.snap_n), nat.ptr(self.vstate), None, None,
                                                nat.ptr(self.inter_state), nat.ptr(self.inter_rows), nat.ptr(self.inter_summary)))
 
+    def enqueue_bev(self, stream=None, frame=None, n_candidates=10):
+        """BEV panels of every stream (BEVRenderer.render, bev_renderer.py:286-348) for one frame of the window, built and
+        painted on the device from the tables the step left in HBM; call where tracker, Kalman and planner outputs are
+        complete (after the join).  Results: self.bev (uint8 [S, 600, 600, 3]).  The trails come from the tracker's
+        history rings, i.e. they are those of the window's last frame (the default)."""
+        from .visualization.bev_renderer import BEVRenderer
+        if not (self.keep_waypoints and self.keep_snapshots):
+            raise RuntimeError("enqueue_bev needs keep_waypoints=True and keep_snapshots=True")
+        if not hasattr(self, "bev"):
+            r = BEVRenderer(device=self.dev.index)
+            self._bev_cfg = nat.BevCfg(r.width, r.height, r.pixels_per_meter, r.x_range[0], r.x_range[1], r.y_range[0], r.y_range[1],
+                                       n_candidates, 0)
+            self._bev_cap = int(self.L.av_bev_prim_cap(C.byref(self._bev_cfg), self.tcap, self.n_points))
+            self._bev_base = torch.as_tensor(r.create_base_image()).to(self.dev)
+            self.bev = torch.empty(self.S, r.height, r.width, 3, dtype=torch.uint8, device=self.dev)
+            self._bev_prims = torch.zeros(self.S, self._bev_cap, nat.PRIM_BYTES, dtype=torch.uint8, device=self.dev)
+            self._bev_n = torch.zeros(self.S, dtype=torch.int32, device=self.dev)
+        st = stream or self._s
+        f = self.W - 1 if frame is None else frame
+        with torch.cuda.stream(self.stream):
+            self.bev.copy_(self._bev_base.unsqueeze(0).expand_as(self.bev))
+        nat.check(self.L.av_bev_build(self.ctx.handle, st, C.byref(self._bev_cfg), self.S, self.W, f, self.tcap,
+                                      self.tcfg.trajectory_length, nat.ptr(self.snap), nat.ptr(self.snap_n), nat.ptr(self.trk_state),
+                                      nat.ptr(self.vstate), nat.ptr(self.wp), nat.ptr(self.order), nat.ptr(self._bev_prims),
+                                      self._bev_cap, nat.ptr(self._bev_n)))
+        nat.check(self.L.av_raster_draw(self.ctx.handle, st, self.S, self._bev_cfg.height, self._bev_cfg.width, nat.ptr(self.bev),
+                                        nat.ptr(self._bev_prims), self._bev_cap, nat.ptr(self._bev_n), None, 0))
+
     def enqueue_plan(self, stream=None):
         nat.check(self.L.av_planner_plan(self.ctx.handle, stream or self._s, self.S * self.W,
                                          nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),

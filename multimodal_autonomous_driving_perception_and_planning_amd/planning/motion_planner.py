@@ -217,29 +217,29 @@ class MotionPlanner:
 
     def draw_trajectories(self, frame: np.ndarray, optimal: Optional[Trajectory], candidates: List[Trajectory],
                           transform_func=None, draw_all: bool = True) -> np.ndarray:
-        """Polyline rendering (display only, not on the hot path)."""
-        import cv2
-        out = frame.copy()
+        """Candidate and optimal paths over a camera frame (motion_planner.py:305-370), drawn by the device rasteriser."""
+        from ..visualization._prims import PrimList, paint
         if transform_func is None:
             h, w = frame.shape[:2]
 
             def transform_func(x, y):
                 return int(w / 2 + x * 10), int(h - y * 10 - 50)
+        pl = PrimList()
         if draw_all:
             worst = max((t.cost for t in candidates), default=0.0) + 1
             for t in candidates:
                 if t == optimal or len(t.waypoints) < 2:
                     continue
                 ratio = t.cost / worst
-                pts = np.array([transform_func(w.x, w.y) for w in t.waypoints]).reshape((-1, 1, 2)).astype(np.int32)
-                cv2.polylines(out, [pts], False, (0, int(255 * (1 - ratio)), int(255 * ratio)), 1)
+                pl.polylines([transform_func(x, y) for x, y in t.get_positions()], False, (0, int(255 * (1 - ratio)), int(255 * ratio)), 1)
         if optimal and len(optimal.waypoints) >= 2:
-            pts = np.array([transform_func(w.x, w.y) for w in optimal.waypoints]).reshape((-1, 1, 2)).astype(np.int32)
-            cv2.polylines(out, [pts], False, (0, 255, 0), 4)
-            cv2.polylines(out, [pts], False, (100, 255, 100), 2)
-            for w in optimal.waypoints[::5]:
-                cv2.circle(out, transform_func(w.x, w.y), 3, (255, 255, 0), -1)
-        return out
+            pos = optimal.get_positions()
+            pts = [transform_func(x, y) for x, y in pos]
+            pl.polylines(pts, False, (0, 255, 0), 4)
+            pl.polylines(pts, False, (100, 255, 100), 2)
+            for x, y in pos[::5]:
+                pl.circle(transform_func(x, y), 3, (255, 255, 0), -1)
+        return paint(frame, pl, self._dev.index)
 
     def reset(self):
         self.reference_trajectory = None

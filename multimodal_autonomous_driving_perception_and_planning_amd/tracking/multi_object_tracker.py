@@ -209,27 +209,24 @@ class MultiObjectTracker:
 
     def draw_tracks(self, frame: np.ndarray, tracks: List[Track], draw_trajectories: bool = True,
                     draw_ids: bool = True, draw_velocities: bool = False) -> np.ndarray:
-        """Boxes, ids, trails (display only, not on the hot path)."""
-        import cv2
-        out = frame.copy()
-        palette = [(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (255, 0, 255), (0, 255, 255),
-                   (128, 0, 255), (255, 128, 0)]
+        """Boxes, ids, trails, velocity arrows (multi_object_tracker.py:251-313), drawn by the device rasteriser."""
+        from ..visualization._prims import PrimList, paint
+        palette = [(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (255, 0, 255), (0, 255, 255), (128, 0, 255), (255, 128, 0)]
+        pl = PrimList()
         for t in tracks:
             col = palette[t.track_id % len(palette)]
             x1, y1, x2, y2 = t.bbox
-            cv2.rectangle(out, (x1, y1), (x2, y2), col, 2)
+            pl.rectangle((x1, y1), (x2, y2), col, 2)
             if draw_ids:
-                cv2.putText(out, "ID:%d %s" % (t.track_id, t.class_name), (x1, y1 - 10), cv2.FONT_HERSHEY_SIMPLEX,
-                            0.5, col, 2)
+                pl.put_text("ID:%d %s" % (t.track_id, t.class_name), (x1, y1 - 10), 0.5, col, 2)
             if draw_trajectories and len(t.trajectory) > 1:
                 pts = np.array(t.trajectory, dtype=np.int32)
                 for i in range(1, len(pts)):
-                    cv2.line(out, tuple(pts[i - 1]), tuple(pts[i]), col, max(1, int(3 * i / len(pts))))
+                    pl.line(tuple(pts[i - 1]), tuple(pts[i]), col, max(1, int(3 * i / len(pts))))
             if draw_velocities and t.velocity:
                 cx, cy = int(t.center[0]), int(t.center[1])
-                cv2.arrowedLine(out, (cx, cy), (int(cx + t.velocity[0] * 5), int(cy + t.velocity[1] * 5)),
-                                (0, 255, 255), 2, tipLength=0.3)
-        return out
+                pl.arrowed_line((cx, cy), (int(cx + t.velocity[0] * 5), int(cy + t.velocity[1] * 5)), (0, 255, 255), 2, tip_length=0.3)
+        return paint(frame, pl, self._dev.index)
 
     def reset(self):
         self.tracks.clear()
