@@ -364,6 +364,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     loop = PerceptionLoop(n_streams=S, device=local)
     L = nat.lib()
     s, side = loop._s, loop.ctx.side_stream
+    if not a.no_defer:
+        loop.defer_detector_tail(True)       # decode + sort + NMS of step k beside the convolutions of step k+1
 
     def one_step():
         # PerceptionLoop.step_deferred(): the lane chain runs beside the detector on the side stream (both only read
@@ -397,6 +399,7 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     el = time.perf_counter() - t0
     el, per_rank_ms = max_over_ranks(el, world)
 
+    loop.defer_detector_tail(False)          # the per-stage times below are of whole stages
     sync = loop.synchronize
     t_gen = time_stage(L, nat, s, loop.enqueue_generate, stage_reps, sync)
     t_yolo = time_stage(L, nat, s, loop.enqueue_detect, stage_reps, sync)

@@ -294,6 +294,12 @@ int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors);     
  *   det_conf float [batch][max_det]; det_cls int32 [batch][max_det]; rows in descending confidence */
 int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float conf_thres, float iou_thres,
                     int max_det, int32_t* det_n, float* det_box, float* det_conf, int32_t* det_cls);
+/* Throughput mode: with the tail deferred, av_yolo_forward enqueues decode + sort + NMS on a stream of its own behind the
+ * head convolutions, so that they run beside the NEXT forward's convolutions (one workgroup per image for ~0.25 ms is the
+ * latency-bound end of the chain).  Same kernels and results; det_* are complete once `stream` has passed
+ * av_yolo_join_tail().  Forwards of one handle still execute in call order. */
+int av_yolo_defer_tail(av_yolo* h, int enable);
+int av_yolo_join_tail(av_yolo* h, av_stream_t stream);
 /* Test hook: device pointer + geometry of an intermediate NHWC tensor (bf16; ids = yolov8.yaml layer
  * numbers, 0 = network input: RGB in 4-channel pixels inside a one-pixel frame of zeros, [H+2][W+2]; 100+2i / 101+2i =
  * float32 box / class logits of level i). */

@@ -636,6 +636,12 @@ struct Yolo {
     struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; };   // lane 1: internal side stream
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // deferred tail (throughput mode): decode + sort + NMS of forward k run on their own stream beside the convolutions
+    // of forward k+1 -- they occupy one workgroup per image and ~0.25 ms, the latency-bound end of an otherwise
+    // chip-wide chain.  Outputs are complete after av_yolo_join_tail().
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_heads = nullptr, ev_decoded = nullptr, ev_tail = nullptr;
+    bool defer_tail = false, tail_pending = false;
     int head_begin = -1;                 // first op of the head (everything before it is one dependency chain)
     std::vector<Op> ops;
     std::vector<void*> allocs;
@@ -796,6 +802,10 @@ int av_yolo_destroy(av_yolo* h) {
     if (!h) return AV_OK;
     for (void* p : h->y.allocs) (void)hipFree(p);
     if (h->y.side) (void)hipStreamDestroy(h->y.side);
+    if (h->y.tail) (void)hipStreamDestroy(h->y.tail);
+    if (h->y.ev_heads) (void)hipEventDestroy(h->y.ev_heads);
+    if (h->y.ev_decoded) (void)hipEventDestroy(h->y.ev_decoded);
+    if (h->y.ev_tail) (void)hipEventDestroy(h->y.ev_tail);
     if (h->y.ev_fork) (void)hipEventDestroy(h->y.ev_fork);
     if (h->y.ev_join) (void)hipEventDestroy(h->y.ev_join);
     delete h;
@@ -951,6 +961,8 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     }
     for (size_t oi = 0; oi < y.ops.size(); ++oi) {
         const Yolo::Op& op = y.ops[oi];
+        if ((int)oi == y.head_begin && y.tail_pending)     // the previous forward's decode must have read the logits the head rewrites
+            AV_HIP(hipStreamWaitEvent(st_main, y.ev_decoded, 0));
         if (y.side && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
             AV_HIP(hipEventRecord(y.ev_fork, st_main));
             AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
@@ -1012,6 +1024,11 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         AV_HIP(hipEventRecord(y.ev_join, y.side));
         AV_HIP(hipStreamWaitEvent(st_main, y.ev_join, 0));
     }
+    if (y.defer_tail) {                                    // the rest goes to the tail stream, behind the head
+        AV_HIP(hipEventRecord(y.ev_heads, st_main));
+        AV_HIP(hipStreamWaitEvent(y.tail, y.ev_heads, 0));
+        st = y.tail;
+    }
     Level lv[3];
     int aoff = 0;
     const int strides[3] = {8, 16, 32};
@@ -1022,6 +1039,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.cbox, y.cconf,
                        y.ccls);
     AV_LAUNCH_CHECK();
+    if (y.defer_tail) AV_HIP(hipEventRecord(y.ev_decoded, st));
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, st, y.A, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
     AV_LAUNCH_CHECK();
     // gain/pad of ultralytics scale_boxes
@@ -1031,6 +1049,32 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(64 * NMS_WAVES), nms_lds, st, y.A, max_det, iou_thres, y.sbox, y.scount, y.sidx,
                        y.cbox, y.cconf, y.ccls, gain, padx, pady, (float)y.inW, (float)y.inH, det_n, det_box, det_conf, det_cls);
     AV_LAUNCH_CHECK();
+    if (y.defer_tail) {
+        AV_HIP(hipEventRecord(y.ev_tail, st));
+        y.tail_pending = true;
+    }
+    return AV_OK;
+}
+
+int av_yolo_defer_tail(av_yolo* h, int enable) {
+    AV_REQUIRE(h, AV_EINVAL, "av_yolo_defer_tail: null handle");
+    Yolo& y = h->y;
+    if (enable && !y.tail) {
+        AV_HIP(hipStreamCreateWithFlags(&y.tail, hipStreamNonBlocking));
+        AV_HIP(hipEventCreateWithFlags(&y.ev_heads, hipEventDisableTiming));
+        AV_HIP(hipEventCreateWithFlags(&y.ev_decoded, hipEventDisableTiming));
+        AV_HIP(hipEventCreateWithFlags(&y.ev_tail, hipEventDisableTiming));
+    }
+    y.defer_tail = enable != 0;
+    return AV_OK;
+}
+
+int av_yolo_join_tail(av_yolo* h, av_stream_t stream) {
+    AV_REQUIRE(h, AV_EINVAL, "av_yolo_join_tail: null handle");
+    if (h->y.tail_pending) {
+        AV_HIP(hipStreamWaitEvent(as_stream(stream), h->y.ev_tail, 0));
+        h->y.tail_pending = false;
+    }
     return AV_OK;
 }
 

@@ -328,6 +328,14 @@ class PerceptionLoop:
         if sync:
             self.stream.synchronize()
 
+    def defer_detector_tail(self, enable=True):
+        """Throughput mode of the detector: decode + sort + NMS of step k beside the convolutions of step k+1
+        (av_yolo_defer_tail); det_* are complete after flush_lanes() / join_detector_tail()."""
+        nat.check(self.L.av_yolo_defer_tail(self.yolo._h, 1 if enable else 0))
+
+    def join_detector_tail(self):
+        nat.check(self.L.av_yolo_join_tail(self.yolo._h, self._s))
+
     def step_deferred(self):
         """Throughput variant of step(): the Hough + fit half of a frame's lane chain is enqueued one step late, ahead
         of the next frame's pixel stages on the side stream.  The sharded PPHT holds 158 KB of LDS on every CU it
@@ -349,6 +357,7 @@ class PerceptionLoop:
         if self._lanes_pending:
             self.enqueue_lanes(stages=16)
             self._lanes_pending = False
+        self.join_detector_tail()
 
     def synchronize(self):
         self.stream.synchronize()

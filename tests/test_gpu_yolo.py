@@ -239,6 +239,15 @@ def test_perception_loop_step_matches_per_frame_paths(setup):
     loop2.synchronize()
     torch.cuda.synchronize()
     assert lanes_equal(2)
+    # detector tail (decode + sort + NMS) deferred onto its own stream beside the next step's convolutions: same detections
+    loop3 = PerceptionLoop(n_streams=S, h=h, w=w)
+    loop3.defer_detector_tail(True)
+    for step in range(3):
+        loop3.step_deferred()
+    loop3.flush_lanes()                     # also joins the detector's tail
+    loop3.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(loop3.det_n.cpu().numpy(), seen[2][4]) and np.array_equal(loop3.det_box.cpu().numpy(), seen[2][5])
 
 
 def test_two_to_one_preprocess_equals_generic_kernel(setup, monkeypatch):
