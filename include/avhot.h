@@ -270,7 +270,8 @@ int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segmen
  *   stages     bit0: also write the pre-ROI Canny edge map (view 2); bit1: stop after the pixel stages
  *              (no Hough, no fit); bit4: skip the pixel stages and run Hough + fit on what the last bit1 call left
  *              in the workspace -- the two halves of a frame can then be enqueued apart, e.g. the Hough half beside
- *              the next frame's LDS-free kernels (it holds most of a CU's LDS) */
+ *              the next frame's LDS-free kernels (it holds most of a CU's LDS); bit5 (with bit4): fit only, on the
+ *              segment list already in the workspace (views 5 / 6) -- a test hook for the least-squares stage */
 int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int n_streams, int h, int w,
                    const uint8_t* bgr, const int32_t* roi_rows, void* workspace, double* lane_state,
                    double* poly, int32_t* pts, int32_t* info, double* conf, int stages);

@@ -2442,6 +2442,12 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     }
     if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)
     HoughCfg hc{cfg->hough_threshold, cfg->min_line_length, cfg->max_line_gap, cfg->max_segments};
+    if (stages & 32) {                                             // bit 5 (with bit 4): fit only, on the segments in the workspace
+        hipLaunchKernelGGL(lane_fit_kernel, dim3(n_streams * 2), dim3(64), 0, st, n_streams, h, w, cfg->max_segments,
+                           cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     int* fb = rowcnt;       // the per-row counters are dead after compaction: reuse [s*h] as the fallback flag
     const bool use_fast = !(stages & 8);
     if (use_fast) {
