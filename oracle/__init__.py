@@ -22,6 +22,8 @@ Pinning status:
   lane_ref (L1-L7)    PARITY UNPINNED: OpenCV is not installed; restates
                       OpenCV 4.x semantics for cvtColor/GaussianBlur/Canny/
                       fillPoly/HoughLinesP from their published algorithms.
+  raster_ref (f-2)    PARITY UNPINNED: the reference draws with cv2; this states the
+                      project's own pixel rules for the geometry of those calls.
   yolo_ref (D2)       PARITY UNPINNED: ultralytics is not installed and
                       yolov8n.pt is absent; PyTorch-CPU fp32 module with the
                       YOLOv8n topology and seeded random weights.
