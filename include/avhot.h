@@ -418,6 +418,13 @@ int av_bev_build(av_ctx* ctx, av_stream_t stream, const av_bev_cfg* cfg, int n_s
 int av_resize_into(av_ctx* ctx, av_stream_t stream, const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, int dst_pitch_px,
                    int dst_x0);
 
+/* ---- video ingest ----------------------------------------------------------------
+ * The pixel half of VideoDataLoader.read_frame / read_frame_at (data/loaders/video_loader.py:88-131): what a decoder hands over
+ * as planar YUV 4:2:0 becomes the BGR frame cv2.VideoCapture.read returns, then av_resize_into scales it to target_size
+ * (:103-104).  Bitstream decoding is NOT here (no decoder in this image): the loader reads uncompressed containers.
+ *   yuv  u8 [n_frames][h*w*3/2]  I420: Y plane, then U, then V (each (h/2) x (w/2));   bgr  u8 [n_frames][h][w][3] */
+int av_i420_to_bgr(av_ctx* ctx, av_stream_t stream, int n_frames, int h, int w, const uint8_t* yuv, uint8_t* bgr);
+
 /* ---- synthetic input ---------------------------------------------------
  * Deterministic 8-bit BGR road scenes generated on the device, standing in for the reference's lost
  * SyntheticDataGenerator (data/generators, source absent).  Frame (stream0+s, frame) is bit-identical to

@@ -117,6 +117,7 @@ _SIGS = [
     ("av_raster_draw", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int]),
     ("av_bev_prim_cap", C.c_int, [vp, C.c_int, C.c_int]),
     ("av_bev_build", C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+    ("av_i420_to_bgr", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     ("av_resize_into", C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("av_synth_frames", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("av_maneuver_reset", C.c_int, [vp, vp, C.c_int, vp]),

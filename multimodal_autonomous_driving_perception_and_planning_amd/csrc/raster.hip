@@ -410,6 +410,29 @@ __global__ void __launch_bounds__(256) bev_build_kernel(int n_streams, int n_fra
     }
 }
 
+// f-4: planar YUV 4:2:0 (I420) -> interleaved BGR, the pixel work of video ingest (what a decoder hands
+// over; cv2.VideoCapture.read returns BGR, video_loader.py:96-106).  ITU-R BT.601 limited range in OpenCV's 20-bit fixed
+// point (cvtColor COLOR_YUV2BGR_I420: CY 1220542, CUB 2116026, CUG -409993, CVG -852492, CVR 1673527), restated from its
+// published source -- parity unpinned.  A thread makes two horizontally adjacent pixels (they share a chroma sample).
+__global__ void i420_to_bgr_kernel(const uint8_t* __restrict__ yuv, int n, int h, int w, uint8_t* __restrict__ bgr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w2 = w >> 1;
+    if (i >= n * h * w2) return;
+    const int f = i / (h * w2), r = i - f * h * w2, y = r / w2, x = (r - y * w2) * 2;
+    const size_t fsz = (size_t)h * w * 3 / 2;
+    const uint8_t* Y = yuv + (size_t)f * fsz;
+    const uint8_t* U = Y + (size_t)h * w;
+    const uint8_t* V = U + (size_t)(h >> 1) * w2;
+    const int u = (int)U[(size_t)(y >> 1) * w2 + (x >> 1)] - 128, v = (int)V[(size_t)(y >> 1) * w2 + (x >> 1)] - 128;
+    const int ruv = (1 << 19) + 1673527 * v, guv = (1 << 19) - 852492 * v - 409993 * u, buv = (1 << 19) + 2116026 * u;
+    uint8_t* o = bgr + ((size_t)f * h * w + (size_t)y * w + x) * 3;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int yy = max(0, (int)Y[(size_t)y * w + x + k] - 16) * 1220542;
+        const int b = (yy + buv) >> 20, g = (yy + guv) >> 20, rr = (yy + ruv) >> 20;
+        o[3 * k] = (uint8_t)min(max(b, 0), 255), o[3 * k + 1] = (uint8_t)min(max(g, 0), 255), o[3 * k + 2] = (uint8_t)min(max(rr, 0), 255);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -447,6 +470,15 @@ int av_bev_build(av_ctx* ctx, av_stream_t stream, const av_bev_cfg* cfg, int n_s
     hipLaunchKernelGGL(bev_build_kernel, dim3(n_streams), dim3(256), 0, as_stream(stream), n_streams, n_frames, frame, *cfg, tcap,
                        trajectory_length, snap, snap_n, (const uint8_t*)tracker_state, av_tracker_state_bytes(tcap, trajectory_length),
                        vstate, waypoints, order, ctx->n_cand, ctx->n_points, prim_cap, prims, n_prims);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_i420_to_bgr(av_ctx* ctx, av_stream_t stream, int n_frames, int h, int w, const uint8_t* yuv, uint8_t* bgr) {
+    AV_REQUIRE(ctx && yuv && bgr, AV_EINVAL, "av_i420_to_bgr: null argument");
+    AV_REQUIRE(n_frames > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, AV_EINVAL, "av_i420_to_bgr: 4:2:0 frames need even sizes, got %dx%d", w, h);
+    const long n = (long)n_frames * h * (w / 2);
+    hipLaunchKernelGGL(i420_to_bgr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), yuv, n_frames, h, w, bgr);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -179,3 +179,53 @@ def test_device_built_bev_panels_match_the_class_renderer(gpu):
         diff = (got[s] != want).any(axis=2)
         assert len(tracks) > 0 and diff.mean() < 2e-4, (s, float(diff.mean()))
         assert np.array_equal(got[s][:60, :120], want[:60, :120])                   # the legend corner, exactly
+
+
+def test_video_loader_uncompressed_formats(gpu, tmp_path):
+    """f-4: VideoDataLoader on a Y4M (4:2:0) and a .npy file -- the reference's surface (video_loader.py:14-259), frames
+    converted / resized on the device and equal to the oracle's conversion; compressed containers are refused loudly."""
+    from data.loaders.video_loader import VideoDataLoader
+    from data import VideoDataLoader as V2
+    from oracle import raster_ref as R
+    assert V2 is VideoDataLoader
+    rng = np.random.RandomState(9)
+    h, w, n = 48, 64, 5
+    frames_yuv = [rng.randint(0, 256, size=h * w * 3 // 2).astype(np.uint8) for _ in range(n)]
+    p = tmp_path / "clip.y4m"
+    with open(p, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for fr in frames_yuv:
+            f.write(b"FRAME\n" + fr.tobytes())
+    ld = VideoDataLoader(str(p))
+    assert (len(ld), ld.total_frames, ld.fps, ld.width, ld.height, ld.dt) == (n, n, 25.0, w, h, 1 / 25.0)
+    assert abs(ld.duration - n / 25.0) < 1e-12 and ld.get_info()["total_frames"] == n
+    want = [R.i420_to_bgr(fr, h, w) for fr in frames_yuv]
+    got = list(ld)
+    assert len(got) == n and all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert np.array_equal(ld.read_frame_at(3), want[3]) and ld.frame_count == 4
+    assert ld.read_frame_at(n) is None and ld.read_frame_at(-1) is None
+    assert np.array_equal(ld.read_frame(), want[4]) and ld.read_frame() is None            # end of video
+    ld.reset()
+    assert len(list(ld.generate_video_stream(2))) == 2
+    np.random.seed(3)
+    ego = ld.generate_ego_motion()
+    assert len(ego) == n and len(ego[0]) == 4
+    # target_size: resized on the device like the oracle's bilinear rule; a batch stays in HBM
+    ld2 = VideoDataLoader(str(p), target_size=(40, 30))
+    assert (ld2.width, ld2.height) == (40, 30)
+    assert np.array_equal(ld2.read_frame_at(1), R.resize(want[1], 30, 40))
+    batch = ld2.read_frames_device(0, n)
+    assert batch.is_cuda and tuple(batch.shape) == (n, 30, 40, 3) and np.array_equal(batch[4].cpu().numpy(), R.resize(want[4], 30, 40))
+    # .npy container
+    arr = rng.randint(0, 256, size=(3, 20, 24, 3)).astype(np.uint8)
+    q = tmp_path / "clip.npy"
+    np.save(q, arr)
+    ld3 = VideoDataLoader(str(q))
+    assert len(ld3) == 3 and np.array_equal(ld3.read_frame_at(2), arr[2])
+    ld3.release()
+    assert ld3.read_frame() is None
+    with pytest.raises(FileNotFoundError):
+        VideoDataLoader(str(tmp_path / "missing.mp4"))
+    (tmp_path / "x.mp4").write_bytes(b"\x00\x00\x00\x18ftypmp42")
+    with pytest.raises(ValueError, match="decoder"):
+        VideoDataLoader(str(tmp_path / "x.mp4"))
