@@ -72,37 +72,63 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias now, consumed once before the first store: gfx9's single in-order vmcnt would otherwise make every bias wait in
+    // the epilogue a wait for the stores before it
+    float4 bsv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch_base + mt * 16 + 4 * h);
     int k = 8 * h, tap = k / a.cin, ci = k - tap * a.cin;
     const half_t* wrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.wgt + (size_t)(ch_base + mt * 16 + l15) * a.kpad + 8 * h;
-    for (int k0 = 0; k0 < a.kpad; k0 += 32) {
+    // Operands come straight from global memory (weights: L2), so a K step's latency is a memory latency: a ring of D steps is
+    // kept in flight -- step s + D is requested right after step s's MFMAs (the stride-2 layers at P4/P5 have 18-36 steps and
+    // about one workgroup per CU: without the ring every step paid the latency in turn, 52 us for 9 GFLOP).
+    constexpr int D = MT >= 4 ? 4 : 6;
+    half8 A[D][MT], Bf[D][NT];
+    const int nsteps = a.kpad / 32;
+    int ld_step = 0;                                        // next step to request; tap / ci follow it
+    auto request = [&](int slot) {
+        const int k0 = ld_step * 32;
         const int ky = a.ksz == 1 ? 0 : tap / 3, kx = a.ksz == 1 ? 0 : tap - ky * 3;
         const bool kv = (k0 + 8 * h) < a.kreal;
-        half8 A[MT], B[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const half8*>(wrow[mt] + k0);
+        for (int mt = 0; mt < MT; ++mt) A[slot][mt] = *reinterpret_cast<const half8*>(wrow[mt] + k0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int iy = iy0[nt] + ky, ix = ix0[nt] + kx;
             const bool ok = kv && pv[nt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ok) v = *reinterpret_cast<const half8*>(a.in + ((size_t)(nb[nt] + iy) * a.W + ix) * a.in_cs + a.in_coff + ci);
-            B[nt] = v;
+            Bf[slot][nt] = v;
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
         ci += 32;
         while (ci >= a.cin) ci -= a.cin, ++tap;
+        ++ld_step;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) request(d);
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (s0 + d < nsteps) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[d][mt], Bf[d][nt], acc[mt][nt], 0, 0, 0);
+                if (ld_step < nsteps) request(d);
+            }
+        }
     }
     // epilogue: lane holds channels ch_base + mt*16 + 4h + {0..3} of pixel pix_base + nt*16 + l15
 #pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(bsv[mt].x), "v"(bsv[mt].y), "v"(bsv[mt].z), "v"(bsv[mt].w));
+#pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ch = ch_base + mt * 16 + 4 * h;
-        const float4 bs = *reinterpret_cast<const float4*>(a.bias + ch);
+        const float4 bs = bsv[mt];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (!pv[nt]) continue;
@@ -194,17 +220,17 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     gload(0);
     // bias and residual of this lane's outputs are fetched now: in the epilogue their latency would be exposed
     float4 bsv[MT];
-    half4 resv[MT][2];
+    uint2 resv[MT][2];                                   // raw halves; outside the map: pixel 0, never used
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ch = ch_base + mt * 16 + 4 * h;
         bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            resv[mt][nt] = make_half4(0.f, 0.f, 0.f, 0.f);
+            resv[mt][nt] = make_uint2(0, 0);
             const int oy = oy0 + 2 * wave + nt, ox = ox0 + l15;
-            if (a.res && oy < a.Ho && ox < a.Wo)
-                resv[mt][nt] = *reinterpret_cast<const half4*>(a.res + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.res_cs + a.res_coff + ch);
+            const size_t rp = (oy < a.Ho && ox < a.Wo) ? ((size_t)n * a.Ho + oy) * a.Wo + ox : 0;
+            if (a.res) resv[mt][nt] = *reinterpret_cast<const uint2*>(a.res + rp * a.res_cs + a.res_coff + ch);
         }
     }
     for (int c0 = 0; c0 < a.cin; c0 += LT_CK) {
@@ -233,6 +259,12 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
         }
     }
+    // one wait for bias and residual before the first store (see conv3x3_ws_kernel)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        asm volatile("" ::"v"(bsv[mt].x), "v"(bsv[mt].y), "v"(bsv[mt].z), "v"(bsv[mt].w));
+        asm volatile("" ::"v"(resv[mt][0].x), "v"(resv[mt][0].y), "v"(resv[mt][1].x), "v"(resv[mt][1].y));
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ch = ch_base + mt * 16 + 4 * h;
@@ -247,7 +279,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
             if (a.res) {
-                const half4 rr = resv[mt][nt];
+                const half4 rr = *reinterpret_cast<const half4*>(&resv[mt][nt]);
                 v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
             }
             if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
@@ -569,6 +601,199 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
                     if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
                     else *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
                 }
+            }
+        }
+    }
+}
+
+// Fused C2f block with 16 hidden channels, one bottleneck, shortcut (layer 2 of the network, the 1/4-resolution map: 983k
+// pixels per 64 frames).  Its four convolutions (cv1 1x1 32->32, 3x3 16->16, 3x3 16->16 + residual, cv2 1x1 48->32) move
+// 63 + 63 MB when fused; as four launches they moved 440 MB and took 130 us, every one of them HBM-bound.  A workgroup owns a
+// 16x16 output tile: the input patch with a 2-pixel halo (20x20x32) goes to LDS once, cv1 runs in place on it (y0 | y1),
+// the first 3x3 writes its 18x18x16 result to a second LDS image, the second 3x3's result (y2) takes a 512-byte per-wave
+// detour through LDS into operand layout, and cv2 consumes y0 | y1 | y2.  All four weight matrices stay in LDS for the
+// workgroup's life.  The arithmetic is the unfused layers' to the bit: the same K = 32 MFMA steps in the same order (16-channel
+// operands zero-padded to 32 exactly as conv3x3_ws_kernel / conv_mfma_kernel pad them), the same epilogue expressions,
+// intermediates rounded to half at the same points; positions outside the image hold zeros (the 3x3 convolutions' padding).
+// tests/test_gpu_yolo.py compares the two paths bit for bit.
+struct C2f16Args {
+    const half_t* in;  int in_cs, in_coff;
+    half_t* out;       int out_cs, out_coff;
+    int H, W, tiles_x, tiles_y, n_tiles;
+    const half_t *w_cv1, *w_b1, *w_b2, *w_cv2;      // [32][32], [16][kb], [16][kb], [32][kc]: global row strides 32, kb, kb, kc
+    const float *bs_cv1, *bs_b1, *bs_b2, *bs_cv2;
+    int kb, kc;
+};
+
+constexpr int C2F_XW = 20, C2F_TW = 18, C2F_XS = 96, C2F_TS = 32;           // patch widths and pixel strides (bytes, = 32 mod 64)
+constexpr int C2F_NW = 8, C2F_NTH = C2F_NW * 64;                              // waves per workgroup: the MFMA chains of the 3x3 stages are
+// dependent (9 taps onto one accumulator), so the SIMDs need several waves each to stay busy
+constexpr int C2F_W1S = 96, C2F_WBS = 608, C2F_W2S = 160;                    // weight row strides in LDS (= 32 mod 64)
+constexpr int C2F_OFF_T1 = 400 * C2F_XS, C2F_OFF_W1 = C2F_OFF_T1 + 324 * C2F_TS, C2F_OFF_WB1 = C2F_OFF_W1 + 32 * C2F_W1S,
+              C2F_OFF_WB2 = C2F_OFF_WB1 + 16 * C2F_WBS, C2F_OFF_W2 = C2F_OFF_WB2 + 16 * C2F_WBS, C2F_OFF_Y2 = C2F_OFF_W2 + 32 * C2F_W2S,
+              C2F_OFF_Z = C2F_OFF_Y2 + C2F_NW * 16 * 32, C2F_LDS = C2F_OFF_Z + 64;    // Z: 64 zero bytes
+static_assert(2 * C2F_LDS <= 160 * 1024, "two workgroups per CU");
+
+__global__ void __launch_bounds__(C2F_NTH, 2) c2f16_fused_kernel(C2f16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    unsigned char* XY = lsm;                                  // [400][32 ch]: input patch, then cv1's output in place
+    unsigned char* T1 = lsm + C2F_OFF_T1;                     // [324][16 ch]
+    unsigned char* W1 = lsm + C2F_OFF_W1;                     // cv1 [32][32]
+    unsigned char* WB1 = lsm + C2F_OFF_WB1;                   // 3x3 #1 [16][9 taps][16 ch + 16 zeros]
+    unsigned char* WB2 = lsm + C2F_OFF_WB2;
+    unsigned char* W2 = lsm + C2F_OFF_W2;                     // cv2 [32][48 + 16 zeros]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    unsigned char* Y2 = lsm + C2F_OFF_Y2 + wave * 512;        // this wave's [16 px][16 ch]
+    // ---- weights, once ---------------------------------------------------------------------------------------------------
+    for (int i = tid; i < 32 * 4; i += C2F_NTH) *reinterpret_cast<uint4*>(W1 + (i >> 2) * C2F_W1S + (i & 3) * 16) = *reinterpret_cast<const uint4*>(a.w_cv1 + (i >> 2) * 32 + (i & 3) * 8);
+    for (int i = tid; i < 16 * 9 * 4; i += C2F_NTH) {             // piece = 8 channels of one tap; pieces 2, 3 of a tap are the zero padding
+        const int row = i / 36, rem = i - row * 36, tap = rem >> 2, part = rem & 3;
+        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1;
+        if (part < 2) {
+            v1 = *reinterpret_cast<const uint4*>(a.w_b1 + row * a.kb + tap * 16 + part * 8);
+            v2 = *reinterpret_cast<const uint4*>(a.w_b2 + row * a.kb + tap * 16 + part * 8);
+        }
+        *reinterpret_cast<uint4*>(WB1 + row * C2F_WBS + tap * 64 + part * 16) = v1;
+        *reinterpret_cast<uint4*>(WB2 + row * C2F_WBS + tap * 64 + part * 16) = v2;
+    }
+    for (int i = tid; i < 32 * 8; i += C2F_NTH) {
+        const int row = i >> 3, part = i & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (part < 6) v = *reinterpret_cast<const uint4*>(a.w_cv2 + row * a.kc + part * 8);
+        *reinterpret_cast<uint4*>(W2 + row * C2F_W2S + part * 16) = v;
+    }
+    const float4 bs1a = *reinterpret_cast<const float4*>(a.bs_cv1 + 4 * h), bs1b = *reinterpret_cast<const float4*>(a.bs_cv1 + 16 + 4 * h);
+    const float4 bsb1 = *reinterpret_cast<const float4*>(a.bs_b1 + 4 * h), bsb2 = *reinterpret_cast<const float4*>(a.bs_b2 + 4 * h);
+    const float4 bs2a = *reinterpret_cast<const float4*>(a.bs_cv2 + 4 * h), bs2b = *reinterpret_cast<const float4*>(a.bs_cv2 + 16 + 4 * h);
+#define C2F_USE(b) asm volatile("" ::"v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w))
+    C2F_USE(bs1a); C2F_USE(bs1b); C2F_USE(bsb1); C2F_USE(bsb2); C2F_USE(bs2a); C2F_USE(bs2b);              // waited for here, once
+#undef C2F_USE
+    // ---- input patch pieces of this thread: 400 pixels x 4 pieces of 8 channels -----------------------------------------------
+    constexpr int NP = (400 * 4 + C2F_NTH - 1) / C2F_NTH;
+    uint4 pv[NP];
+    auto origin = [&](int t, int& n, int& oy0, int& ox0) {
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
+    };
+    auto gload = [&](int t) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * C2F_NTH, pix = i >> 2, part = i & 3;
+            const int py = pix / C2F_XW, px = pix - py * C2F_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            pv[k] = make_uint4(0, 0, 0, 0);
+            if (i < 1600 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
+        }
+    };
+    if (tid < 4) *reinterpret_cast<uint4*>(lsm + C2F_OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);
+    // 16 channels at p as the B operand of a K = 32 step: lane groups 0, 1 hold them, groups 2, 3 the zero padding -- read from
+    // the zero bytes, so that the load is unconditional and the nine taps' operands can be requested together
+    const unsigned char* zsrc = lsm + C2F_OFF_Z;
+    auto b16 = [&](const unsigned char* p) { return *reinterpret_cast<const half8*>(h < 2 ? p + 16 * h : zsrc); };
+    int t = blockIdx.x;
+    if (t < a.n_tiles) gload(t);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+        __syncthreads();                                       // previous tile done with XY / T1 (and the weights are in)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * C2F_NTH;
+            if (i < 1600) *reinterpret_cast<uint4*>(XY + (i >> 2) * C2F_XS + (i & 3) * 16) = pv[k];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);          // next tile's patch in flight during this tile
+        // ---- cv1 in place: 25 groups of 16 patch pixels, each wave its own ------------------------------------------------
+        for (int g = wave; g < 25; g += C2F_NW) {
+            const int pix = g * 16 + l15;
+            const int py = pix / C2F_XW, px = pix - py * C2F_XW;
+            const bool inside = (unsigned)(oy0 - 2 + py) < (unsigned)a.H && (unsigned)(ox0 - 2 + px) < (unsigned)a.W;
+            unsigned char* xp = XY + pix * C2F_XS;
+            const half8 b = *reinterpret_cast<const half8*>(xp + 16 * h);
+            f32x4 acc[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half8 w = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * C2F_W1S + 16 * h);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            // the MFMAs have read all 32 channels of these 16 pixels (every lane of the wave): in place is safe
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float4 bs = mt ? bs1b : bs1a;
+                float v[4] = {acc[mt][0] + bs.x, acc[mt][1] + bs.y, acc[mt][2] + bs.z, acc[mt][3] + bs.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = inside ? silu(v[q]) : 0.f;      // outside the image: the 3x3 convolutions' zero padding
+                *reinterpret_cast<half4*>(xp + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        // ---- 3x3 #1 on y1 (channels 16..31): 18x18 outputs = 21 groups of 16 -------------------------------------------------
+        for (int g = wave; g < 21; g += C2F_NW) {
+            const int q = g * 16 + l15, qq = q < 324 ? q : 323;
+            const int ty = qq / C2F_TW, tx = qq - ty * C2F_TW;
+            const bool inside = (unsigned)(oy0 - 1 + ty) < (unsigned)a.H && (unsigned)(ox0 - 1 + tx) < (unsigned)a.W;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            half8 bv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) bv[tap] = b16(XY + ((ty + tap / 3) * C2F_XW + tx + tap % 3) * C2F_XS + 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const half8 wv = *reinterpret_cast<const half8*>(WB1 + l15 * C2F_WBS + tap * 64 + 16 * h);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c, 0, 0, 0);
+            }
+            float v[4] = {c[0] + bsb1.x, c[1] + bsb1.y, c[2] + bsb1.z, c[3] + bsb1.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = inside ? silu(v[k]) : 0.f;
+            if (q < 324) *reinterpret_cast<half4*>(T1 + q * C2F_TS + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        // ---- 3x3 #2 + shortcut -> y2, then cv2 on [y0 | y1 | y2]: one output row of 16 pixels per step ----------------------------
+        for (int r = wave; r < 16; r += C2F_NW) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            half8 bv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) bv[tap] = b16(T1 + ((r + tap / 3) * C2F_TW + l15 + tap % 3) * C2F_TS);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const half8 wv = *reinterpret_cast<const half8*>(WB2 + l15 * C2F_WBS + tap * 64 + 16 * h);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c, 0, 0, 0);
+            }
+            const unsigned char* xp = XY + ((r + 2) * C2F_XW + l15 + 2) * C2F_XS;
+            {
+                const half4 rr = *reinterpret_cast<const half4*>(xp + 32 + 8 * h);          // the shortcut: y1
+                float v[4] = {c[0] + bsb2.x, c[1] + bsb2.y, c[2] + bsb2.z, c[3] + bsb2.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
+                *reinterpret_cast<half4*>(Y2 + l15 * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+            }
+            const half8 b01 = *reinterpret_cast<const half8*>(xp + 16 * h);
+            const half8 b2v = b16(Y2 + l15 * 32);               // same wave wrote it: LDS operations of a wave complete in order
+            const int oy = oy0 + r, ox = ox0 + l15;
+            const bool ok = oy < a.H && ox < a.W;
+            half_t* op = a.out + ((size_t)(n * a.H + oy) * a.W + ox) * a.out_cs + a.out_coff + 4 * h;
+            f32x4 o[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half8 wa = *reinterpret_cast<const half8*>(W2 + (mt * 16 + l15) * C2F_W2S + 16 * h);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, b01, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half8 wb = *reinterpret_cast<const half8*>(W2 + (mt * 16 + l15) * C2F_W2S + 64 + 16 * h);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, b2v, o[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float4 bs = mt ? bs2b : bs2a;
+                float v[4] = {o[mt][0] + bs.x, o[mt][1] + bs.y, o[mt][2] + bs.z, o[mt][3] + bs.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+                if (ok) *reinterpret_cast<half4*>(op + mt * 16) = make_half4(v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -952,7 +1177,8 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
-    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; };   // lane 1: internal side stream
+    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; };   // lane 1: internal side stream;
+    // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // deferred tail (throughput mode): decode + sort + NMS of forward k run on their own stream beside the convolutions
@@ -1079,13 +1305,16 @@ bool add_c2f(Yolo& y, Slice in, Slice out, int n, bool shortcut) {
     const int c = out.c / 2, H = bi.H, W = bi.W;
     const int cat = new_buf(y, H, W, (2 + n) * c), tmp = new_buf(y, H, W, c);
     if (cat < 0 || tmp < 0) return false;
+    const size_t first = y.ops.size();
     if (!add_conv(y, in, Slice{cat, 0, 2 * c}, 1, 1, true, nullptr, 0, nullptr)) return false;
     for (int i = 0; i < n; ++i) {
         const Slice src{cat, (1 + i) * c, c}, dst{cat, (2 + i) * c, c};
         if (!add_conv(y, src, Slice{tmp, 0, c}, 3, 1, true, nullptr, 0, nullptr)) return false;
         if (!add_conv(y, Slice{tmp, 0, c}, dst, 3, 1, true, nullptr, 0, shortcut ? &src : nullptr)) return false;
     }
-    return add_conv(y, Slice{cat, 0, (2 + n) * c}, out, 1, 1, true, nullptr, 0, nullptr);
+    if (!add_conv(y, Slice{cat, 0, (2 + n) * c}, out, 1, 1, true, nullptr, 0, nullptr)) return false;
+    if (c == 16 && n == 1 && shortcut && in.c == 32 && out.c == 32) y.ops[first].fuse = 1;
+    return true;
 }
 
 void add_simple(Yolo& y, int kind, Slice in, Slice out, int H, int W, int C) {
@@ -1355,6 +1584,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS));
 #define AV_C1_ATTR(KSV) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<2, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<4, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
@@ -1430,6 +1660,21 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         if (y.side && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
             AV_HIP(hipEventRecord(y.ev_fork, st_main));
             AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
+        }
+        if (op.fuse == 1 && !force_direct && !getenv("AVHOT_YOLO_NO_FUSE")) {      // cv1, 3x3, 3x3 + shortcut, cv2 in one launch
+            const ConvArgs &c1 = op.ca, &b1 = y.ops[oi + 1].ca, &b2 = y.ops[oi + 2].ca, &c2 = y.ops[oi + 3].ca;
+            C2f16Args fa;
+            fa.in = c1.in, fa.in_cs = c1.in_cs, fa.in_coff = c1.in_coff;
+            fa.out = c2.out, fa.out_cs = c2.out_cs, fa.out_coff = c2.out_coff;
+            fa.H = c1.H, fa.W = c1.W, fa.tiles_x = (c1.W + 15) / 16, fa.tiles_y = (c1.H + 15) / 16;
+            fa.n_tiles = fa.tiles_x * fa.tiles_y * B;
+            fa.w_cv1 = c1.wgt, fa.w_b1 = b1.wgt, fa.w_b2 = b2.wgt, fa.w_cv2 = c2.wgt;
+            fa.bs_cv1 = c1.bias, fa.bs_b1 = b1.bias, fa.bs_b2 = b2.bias, fa.bs_cv2 = c2.bias;
+            fa.kb = b1.kpad, fa.kc = c2.kpad;
+            hipLaunchKernelGGL(c2f16_fused_kernel, dim3((unsigned)std::min(fa.n_tiles, 512)), dim3(C2F_NTH), C2F_LDS, st_main, fa);
+            AV_LAUNCH_CHECK();
+            oi += 3;
+            continue;
         }
         const int rc = launch_op(y, op, (y.side && op.lane) ? y.side : st_main, B, force_direct);
         if (rc != AV_OK) return rc;

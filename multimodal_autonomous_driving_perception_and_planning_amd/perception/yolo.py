@@ -127,8 +127,9 @@ class YoloV8n:
         n = int(self._n[0].item())
         return (self._box[0, :n].cpu().numpy(), self._conf[0, :n].cpu().numpy(), self._cls[0, :n].cpu().numpy())
 
-    def tensor(self, tid):
-        """Host copy (float32, [H, W, C]) of an intermediate tensor (test hook)."""
+    def tensor(self, tid, image=0):
+        """Host copy (float32, [H, W, C]) of an intermediate tensor of one image of the batch, or of all images
+        ([batch, H, W, C]) with image=None (test hook)."""
         p, H, W, Cc, cs, co = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         nat.check(self._dev.lib.av_yolo_tensor(self._h, tid, C.byref(p), C.byref(H), C.byref(W), C.byref(Cc), C.byref(cs),
                                                C.byref(co)))
@@ -139,7 +140,9 @@ class YoloV8n:
         rc = _memcpy_d2d(t.data_ptr(), p.value, nbytes)      # the tensor lives in library-owned memory
         if rc != 0:
             raise RuntimeError("hipMemcpy failed (%d)" % rc)
-        arr = t.cpu().numpy().reshape(self.batch, H.value, W.value, cs.value)[0, :, :, co.value:co.value + Cc.value]
+        arr = t.cpu().numpy().reshape(self.batch, H.value, W.value, cs.value)[..., co.value:co.value + Cc.value]
+        if image is not None:
+            arr = arr[image]
         if tid >= 100:
             return arr.astype(np.float32)
         if self.precision == "bf16":                       # (a library built with bf16 activations: comparison runs only)

@@ -153,6 +153,31 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
         assert r["worst_px"] <= 1.0 and r["matched"] >= 0.3 * r["n_want"], r
 
 
+def test_fused_c2f_block_is_bit_identical_to_its_four_launches(setup, monkeypatch):
+    """c2f16_fused_kernel (layer 2: cv1, 3x3, 3x3 + shortcut, cv2 in one launch) against the four-launch path
+    (AVHOT_YOLO_NO_FUSE, read per forward): every element of the block's output, borders included, on frames with
+    different content, in a batch large enough that persistent workgroups walk more than one tile."""
+    import torch
+    Y, R, frame, feats, model, _ = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame] + [synthetic_frame(720, 1280, s, f) for s, f in ((6, 40), (2, 77))] + [np.full((720, 1280, 3), 255, np.uint8)]
+    frames = frames * 3                                  # 12 images = 720 tiles on 512 persistent workgroups: some walk two tiles
+    m = Y.YoloV8n("random:0", batch=len(frames))
+    m._prepare(720, 1280)
+    m._frames.copy_(torch.as_tensor(np.stack(frames)))
+
+    def layer2_all():
+        m.forward_device(m._frames)
+        return m.tensor(2, image=None)
+    fused = layer2_all()
+    monkeypatch.setenv("AVHOT_YOLO_NO_FUSE", "1")
+    unfused = layer2_all()
+    monkeypatch.delenv("AVHOT_YOLO_NO_FUSE")
+    assert fused.shape == (len(frames), 96, 160, 32) and fused.any()
+    assert np.array_equal(fused.view(np.uint32), unfused.view(np.uint32)), int((fused != unfused).sum())
+    m.close()
+
+
 def test_object_detector_yolo_mode(setup):
     from src.perception import ObjectDetector
     Y, R, frame, feats, model, got = setup
