@@ -308,11 +308,13 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 // row stride of an LDS image: the bytes rounded up to = 32 mod 64 (conflict-free ds_read_b128, see conv_lds_kernel)
 constexpr int ws_stride(int bytes) { return bytes + (32 - bytes % 64 + 64) % 64; }
 
-template <int MT, int NT, int NW, int CINP, bool RES>   // NW waves, NT output rows each: tile = NW NT rows x 16 columns
+// S: stride (1 or 2).  With stride 2 neighbouring lanes read pixels two apart, so the pixel stride is = 16 mod 32 bytes
+// (twice that = 32 mod 64) for the same conflict-free reads; the tile is 8 rows x 16 columns of OUTPUT pixels, its patch 17 x 33.
+template <int MT, int NT, int NW, int CINP, bool RES, int S = 1>   // NW waves, NT output rows each: tile = NW NT rows x 16 columns
 __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    constexpr int PH = NW * NT + 2, PW = LT_W + 2, NTH = NW * 64;
-    constexpr int cinp = CINP, pixb = ws_stride(cinp * 2), wrowb = ws_stride(9 * cinp * 2), parts = cinp >> 3;   // 16-byte pieces per pixel
+    constexpr int PH = (NW * NT - 1) * S + 3, PW = (LT_W - 1) * S + 3, NTH = NW * 64;
+    constexpr int cinp = CINP, pixb = S == 1 ? ws_stride(cinp * 2) : cinp * 2 + 16, wrowb = ws_stride(9 * cinp * 2), parts = cinp >> 3;   // 16-byte pieces per pixel
     unsigned char* wts = lsm;
     unsigned char* patch = lsm + (((size_t)16 * MT * wrowb + 15) & ~size_t(15));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
@@ -336,10 +338,10 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
     auto gload = [&](int t) {
         int n, oy0, ox0;
         tile_origin(t, n, oy0, ox0);
-        const half_t* base = a.in + ((long)(n * a.H + oy0 - 1) * a.W + ox0 - 1) * a.in_cs + a.in_coff;
+        const half_t* base = a.in + ((long)(n * a.H + oy0 * S - 1) * a.W + ox0 * S - 1) * a.in_cs + a.in_coff;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int iy = oy0 - 1 + (p_yx[k] >> 16), ix = ox0 - 1 + (p_yx[k] & 0xFFFF);
+            const int iy = oy0 * S - 1 + (p_yx[k] >> 16), ix = ox0 * S - 1 + (p_yx[k] & 0xFFFF);
             pv[k] = make_uint4(0, 0, 0, 0);
             if (p_yx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 pv[k] = *reinterpret_cast<const uint4*>(base + p_rel[k]);
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
         }
     };
     const unsigned char* arow = wts + (size_t)l15 * wrowb;
-    const unsigned char* brow = patch + (size_t)(NT * wave * PW + l15) * pixb;
+    const unsigned char* brow = patch + (size_t)(NT * wave * S * PW + l15 * S) * pixb;
     // K steps: chunk outer, tap inner (conv_lds_kernel's order); 32 channels per step, a last chunk of 16 (cin = 80) goes through
     // the K = 16 MFMA with 8-byte operands (lane group h holds channels 4h .. 4h+3 of the chunk)
     constexpr int NK32 = cinp / LT_CK, NSTEP = 9 * (NK32 + (cinp % LT_CK ? 1 : 0));
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const half8*>(arow + mt * 16 * wrowb + (tap * cinp + c0) * 2 + 16 * h);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const half8*>(brow + ((nt + ky) * PW + kx) * pixb + c0 * 2 + 16 * h);
+            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const half8*>(brow + ((nt * S + ky) * PW + kx) * pixb + c0 * 2 + 16 * h);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const half4 v = *reinterpret_cast<const half4*>(brow + ((nt + ky) * PW + kx) * pixb + c0 * 2 + 8 * h);
+                const half4 v = *reinterpret_cast<const half4*>(brow + ((nt * S + ky) * PW + kx) * pixb + c0 * 2 + 8 * h);
                 B[nt][0] = v.x, B[nt][1] = v.y, B[nt][2] = v.z, B[nt][3] = v.w;
             }
         }
@@ -1375,6 +1377,23 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
                 return AV_OK;
             }
         }
+        // the same kernel for the stride-2 layers whose weights fit (cin <= 64): 8 x 16 output tiles, 17 x 33 patches
+        if (a.stride == 2 && a.ksz == 3 && a.cin % 8 == 0 && !a.res && !force_direct && !getenv("AVHOT_CONV_NO_WS")) {
+            const int cp = (a.cin + 31) & ~31, gy = a.cout / (16 * op.mt);
+            const bool shape2 = a.cout == 16 * op.mt * gy && ((cp == 32 && (op.mt == 2 || op.mt == 4)) || (cp == 64 && op.mt == 4));
+            if (shape2) {
+                const size_t lds = (((size_t)16 * op.mt * ws_stride(9 * cp * 2) + 15) & ~size_t(15)) + (size_t)17 * 33 * (cp * 2 + 16);
+                const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + 7) / 8;
+                const int n_tiles = tiles_x * tiles_y * B;
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+                const dim3 wgrid((unsigned)std::max(1, std::min(n_tiles, 256 * per_cu / gy)), gy);
+                if (cp == 32 && op.mt == 2) hipLaunchKernelGGL((conv3x3_ws_kernel<2, 1, 8, 32, false, 2>), wgrid, dim3(512), lds, st, a, tiles_x, tiles_y, n_tiles);
+                else if (cp == 32) hipLaunchKernelGGL((conv3x3_ws_kernel<4, 1, 8, 32, false, 2>), wgrid, dim3(512), lds, st, a, tiles_x, tiles_y, n_tiles);
+                else hipLaunchKernelGGL((conv3x3_ws_kernel<4, 1, 8, 64, false, 2>), wgrid, dim3(512), lds, st, a, tiles_x, tiles_y, n_tiles);
+                AV_LAUNCH_CHECK();
+                return AV_OK;
+            }
+        }
         // weight-stationary persistent kernel: 3x3 stride 1, the whole weight matrix + one all-channel patch in LDS
         const int cinp = a.cin == 80 ? 80 : (a.cin + 31) & ~31;       // channels per pixel in the LDS image
         const bool ws_shape = a.stride == 1 && a.ksz == 3 && a.cin % 8 == 0 && a.cout == 16 * op.mt &&
@@ -1590,6 +1609,9 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<4, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
     AV_C1_ATTR(1); AV_C1_ATTR(2); AV_C1_ATTR(3); AV_C1_ATTR(4); AV_C1_ATTR(6); AV_C1_ATTR(8); AV_C1_ATTR(12); AV_C1_ATTR(16);
 #undef AV_C1_ATTR
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<2, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 64, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AV_WS_ATTR1(MTV, NTV, NWV, CP) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
