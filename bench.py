@@ -410,8 +410,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     tf = fl / (t_yolo * 1e-3) / 1e12
     pix_bytes = loop.lane_pixel_bytes_per_px * px
     ks = [
-        {"kernel": "yolo forward: preprocess + 63 conv launches (conv_lds_kernel / conv_mfma_kernel / stem) + sppf + "
-                   "upsample + decode + sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
+        {"kernel": "yolo forward: preprocess + stem + fused C2f (layer 2) + 58 conv launches (conv3x3_ws_kernel / "
+                   "conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel) + sppf + upsample + decode + sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
          "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
         {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",

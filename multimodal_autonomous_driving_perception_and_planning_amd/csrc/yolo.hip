@@ -530,10 +530,10 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
 // 32-pixel tiles on its own: all KS = cin / 32 fragments of a tile are requested at once (one exposed latency per tile instead
 // of conv_lds_kernel's one per 32-channel chunk, and no barrier after the weight load); two to four waves per SIMD cover it.
 // Same K order and epilogue as conv_lds_kernel: bit-identical outputs.
-template <int MT, int KS>
+template <int MT, int KS, bool TAIL16 = false>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), via the K = 16 MFMA
 __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    constexpr int NT = 2, cin = KS * 32, wrowb = ws_stride(cin * 2), parts = cin >> 3;
+    constexpr int NT = 2, cin = KS * 32 + (TAIL16 ? 16 : 0), wrowb = ws_stride(cin * 2), parts = cin >> 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     const int ch_base = blockIdx.y * 16 * MT;
     {
@@ -564,14 +564,17 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
     const int wstride = gridDim.x * 4;
     for (int t = blockIdx.x * 4 + wave; t < n_tiles; t += wstride) {
         half8 B[KS][NT];
+        half4 Bt[NT];
         long pix[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const long p = (long)t * 32 + nt * 16 + l15;
             pix[nt] = p;
-            const half_t* src = a.in + (p < a.npix ? p : 0) * a.in_cs + a.in_coff + 8 * h;      // beyond the end: pixel 0, never stored
+            const half_t* px0 = a.in + (p < a.npix ? p : 0) * a.in_cs + a.in_coff;              // beyond the end: pixel 0, never stored
+            const half_t* src = px0 + 8 * h;
 #pragma unroll
             for (int k = 0; k < KS; ++k) B[k][nt] = *reinterpret_cast<const half8*>(src + k * 32);
+            if (TAIL16) Bt[nt] = *reinterpret_cast<const half4*>(px0 + KS * 32 + 4 * h);
         }
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -587,6 +590,18 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[k][nt], acc[mt][nt], 0, 0, 0);
+        }
+        if (TAIL16) {            // (MT NT - 1 other MFMAs lie between this one and the K = 32 MFMA it accumulates onto: see c2f16_fused_kernel)
+            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h4v a4 = *reinterpret_cast<const h4v*>(lsm + (size_t)(mt * 16 + l15) * wrowb + KS * 64 + 8 * h);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const h4v b4 = {Bt[nt].x, Bt[nt].y, Bt[nt].z, Bt[nt].w};
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[mt][nt], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1345,6 +1360,15 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
         // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
         // a partial 32-channel chunk is zero-filled) and for 1x1 with whole chunks; stride 2 and the rest stay direct
         const bool lds_ok = a.stride == 1 && ((a.ksz == 3 && a.cin >= 16 && a.cin % 8 == 0) || (a.ksz == 1 && a.cin % LT_CK == 0));
+        // the head's last class convolution (80 -> 80, float32 logits out): two whole steps + a 16-channel tail
+        if (a.ksz == 1 && a.stride == 1 && a.cin == 80 && a.cout == 80 && op.mt == 5 && !a.res && !force_direct && !getenv("AVHOT_CONV_NO_1X1")) {
+            const size_t lds = (size_t)80 * ws_stride(160);
+            const int n_tiles = (a.npix + 31) / 32;
+            hipLaunchKernelGGL((conv1x1_ws_kernel<5, 2, true>), dim3((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024))), dim3(256), lds, st,
+                               a, n_tiles);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
         // 1x1 with whole 32-channel steps: weights resident in LDS, pixel fragments straight from global memory
         if (a.ksz == 1 && a.stride == 1 && a.cin % 32 == 0 && !a.res && a.cout == 16 * op.mt * (a.cout / (16 * op.mt)) &&
             (op.mt == 2 || op.mt == 4) && !force_direct && !getenv("AVHOT_CONV_NO_1X1")) {

@@ -50,6 +50,15 @@ def counters(name):
 for nm in ("bench_config4", "bench_config3", "bench_config2", "lane_S64", "yolo_b64"):
     stats(nm, "%s_%s_kernel_stats.csv" % (tag, nm))
 
+# ---- YOLO: launch-by-launch timeline of the last forward of the trace (tools/ytimeline.py) ---------------------------------
+_yc = glob.glob(os.path.join(src, "yolo_b64", "*_results.db"))
+if _yc:
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    txt = subprocess.run([sys.executable, os.path.join(here, "ytimeline.py"), _yc[0]], capture_output=True, text=True).stdout
+    with open(os.path.join(dst, "%s_yolo_b64_timeline.txt" % tag), "w") as f:
+        f.write("# one forward of 64 frames, launch by launch (rocprofv3 --kernel-trace -- python3 tools/ybench.py --batch 64 --reps 5)\n" + txt)
+
 # ---- lane: HBM bytes per kernel (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md; both in KiB) -----------------------------
 fe, wr, sq = counters("lane_fetch"), counters("lane_write"), counters("lane_sq")
 S, H, W = 64, 720, 1280
