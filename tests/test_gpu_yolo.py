@@ -46,6 +46,32 @@ def test_preprocess_and_feature_maps(setup):
         assert np.abs(have - want).mean() < 0.0015 * np.abs(want).mean() + 1e-5, key   # measured <= 0.0008
 
 
+def test_feature_maps_at_a_resolution_with_partial_tiles(setup):
+    """600x800 input -> 480x640 network input: the maps are 120x160, 60x80, 30x40, 15x20, so the persistent kernels' 16- and
+    8-row tiles, the stride-2 kernel's 17x33 patches and the fused block's 16x16 tiles all end in partial tiles, and the
+    last stride-2 layer halves an odd height.  Same tolerances as at 720p."""
+    import torch
+    Y, R, frame, feats, model, _ = setup
+    rs = np.random.RandomState(5)
+    fr = rs.randint(0, 256, (600, 800, 3)).astype(np.uint8)
+    fr[200:420, 100:500] = (40, 180, 90)
+    net = R.build_model(R.random_params(0))
+    with torch.no_grad():
+        f = net.features(torch.from_numpy(R.preprocess(fr))[None])
+    m = Y.YoloV8n("random:0")
+    m.detect(fr)
+    assert m.dims()[:2] == (480, 640)
+    for tid, key in ((1, "l1"), (2, "l2"), (4, "l4"), (6, "l6"), (8, "l8"), (9, "l9"), (12, "l12"), (15, "p3"), (18, "p4"), (21, "p5")):
+        want, have = f[key][0].numpy().transpose(1, 2, 0), m.tensor(tid)
+        assert have.shape == want.shape, key
+        assert _rel(have, want) < 0.004, (key, _rel(have, want))
+        assert np.abs(have - want).mean() < 0.0015 * np.abs(want).mean() + 1e-5, key
+    for i, (b, c) in enumerate(f["head"]):
+        assert _rel(m.tensor(100 + 2 * i), b[0].numpy().transpose(1, 2, 0)) < 0.001
+        assert _rel(m.tensor(101 + 2 * i), c[0].numpy().transpose(1, 2, 0)) < 0.001
+    m.close()
+
+
 def test_head_logits_and_decode(setup):
     Y, R, frame, feats, model, _ = setup
     for i, (b, c) in enumerate(feats["head"]):
