@@ -301,9 +301,16 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
  * av_yolo_join_tail().  Forwards of one handle still execute in call order. */
 int av_yolo_defer_tail(av_yolo* h, int enable);
 int av_yolo_join_tail(av_yolo* h, av_stream_t stream);
-/* Test hook: device pointer + geometry of an intermediate NHWC tensor (bf16; ids = yolov8.yaml layer
+/* The Detect head's decode (DFL expectation, best class, sigmoid; reference: ultralytics' Detect via detector.py:103-123)
+ * runs in the epilogue of the head's last convolutions: the float32 logits are normally neither written nor read.  With
+ * keep_logits the head writes them as well and the stand-alone decode kernel runs on them into buffers of its own
+ * (tensor ids 120-122), which is how the tests show that both decodes give the same candidates bit for bit. */
+int av_yolo_keep_logits(av_yolo* h, int enable);
+/* Test hook: device pointer + geometry of an intermediate NHWC tensor (IEEE half; ids = yolov8.yaml layer
  * numbers, 0 = network input: RGB in 4-channel pixels inside a one-pixel frame of zeros, [H+2][W+2]; 100+2i / 101+2i =
- * float32 box / class logits of level i). */
+ * float32 box / class logits of level i, valid after av_yolo_keep_logits(h, 1); 110 / 111 / 112 = the candidates of every
+ * anchor as the head wrote them: box float32 [A][4], confidence float32 [A], class int32 [A]; 120-122 = the same from the
+ * stand-alone decode of the kept logits). */
 int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C, int* cstride, int* coff);
 
 /* ---- T1: maneuver tags ------------------------------------------------------

@@ -130,6 +130,7 @@ _SIGS = [
     ("av_yolo_destroy", C.c_int, [vp]),
     ("av_yolo_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("av_yolo_forward", C.c_int, [vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),
+    ("av_yolo_keep_logits", C.c_int, [vp, C.c_int]),
     ("av_yolo_defer_tail", C.c_int, [vp, C.c_int]),
     ("av_yolo_join_tail", C.c_int, [vp, vp]),
     ("av_yolo_tensor", C.c_int, [vp, C.c_int, C.POINTER(vp)] + [C.POINTER(C.c_int)] * 5),

@@ -530,10 +530,20 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
 // 32-pixel tiles on its own: all KS = cin / 32 fragments of a tile are requested at once (one exposed latency per tile instead
 // of conv_lds_kernel's one per 32-channel chunk, and no barrier after the weight load); two to four waves per SIMD cover it.
 // Same K order and epilogue as conv_lds_kernel: bit-identical outputs.
-template <int MT, int KS, bool TAIL16 = false>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), via the K = 16 MFMA
-__global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles) {
+// DEC: the Detect head's decode in the epilogue of its last convolutions, so that the float32 logits (185 MB per 64 frames) are
+// neither written nor read again.  1: box branch (64 = 4 sides x 16 bins): the tile's logits take a per-wave detour through LDS
+// so that lane group h holds all 16 bins of side h of its pixel, then decode_kernel's arithmetic to the letter (sequential
+// max / exp / sums over the bins, IEEE divide) and one box coordinate per lane.  2: class branch (80 classes): first maximum
+// (lowest class among equals, as decode_kernel's scan) over the lane's 20 values and across the four lane groups, sigmoid.
+// Candidates equal decode_kernel's bit for bit (test_fused_decode_equals_decode_kernel).
+struct DecArgs { float* cbox; float* cconf; int* ccls; int A, aoff, stride, keep_logits; };
+constexpr int DEC_ROW = 68;                        // floats per pixel row of the box detour (64 + 4: conflict-free b128 rows)
+
+template <int MT, int KS, bool TAIL16 = false, int DEC = 0>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), via the K = 16 MFMA
+__global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles, DecArgs dec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     constexpr int NT = 2, cin = KS * 32 + (TAIL16 ? 16 : 0), wrowb = ws_stride(cin * 2), parts = cin >> 3;
+    static_assert(DEC == 0 || (DEC == 1 && MT == 4) || (DEC == 2 && MT == 5), "decode epilogues belong to the 64- and 80-channel head outputs");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     const int ch_base = blockIdx.y * 16 * MT;
     {
@@ -606,6 +616,7 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const long p = pix[nt];
+            float vv[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ch = ch_base + mt * 16 + 4 * h;
@@ -614,9 +625,59 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
                 if (a.act)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
-                if (p < a.npix) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[mt][q] = v[q];
+                if (p < a.npix && (DEC == 0 || dec.keep_logits)) {
                     if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
                     else *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            if (DEC) {
+                const int hw = a.Ho * a.Wo;
+                const long pc = p < a.npix ? p : 0;
+                const int n = (int)(pc / hw), r = (int)(pc - (long)n * hw), y = r / a.Wo, x = r - y * a.Wo;
+                const size_t ci = (size_t)n * dec.A + dec.aoff + r;                      // candidate index, as decode_kernel's
+                if (DEC == 1) {
+                    float* sc = reinterpret_cast<float*>(lsm + (((size_t)16 * MT * wrowb + 15) & ~size_t(15))) + wave * 16 * DEC_ROW;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        *reinterpret_cast<float4*>(sc + l15 * DEC_ROW + mt * 16 + 4 * h) = make_float4(vv[mt][0], vv[mt][1], vv[mt][2], vv[mt][3]);
+                    float b[REG_MAX];                    // side h of pixel l15 (LDS operations of one wave complete in order)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(sc + l15 * DEC_ROW + h * 16 + 4 * k);
+                        b[4 * k] = t4.x, b[4 * k + 1] = t4.y, b[4 * k + 2] = t4.z, b[4 * k + 3] = t4.w;
+                    }
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int j = 0; j < REG_MAX; ++j) mx = fmaxf(mx, b[j]);
+                    float sum = 0.f, ex = 0.f;
+#pragma unroll
+                    for (int j = 0; j < REG_MAX; ++j) {
+                        const float e = __expf(b[j] - mx);
+                        sum += e, ex += e * (float)j;
+                    }
+                    const float d = ex / sum;
+                    const float ac = (h & 1) ? (float)y + 0.5f : (float)x + 0.5f, st = (float)dec.stride;
+                    if (p < a.npix) dec.cbox[ci * 4 + h] = (h < 2 ? ac - d : ac + d) * st;
+                } else {
+                    float best = -INFINITY;
+                    int bj = 0;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (vv[mt][q] > best) best = vv[mt][q], bj = mt * 16 + 4 * h + q;
+#pragma unroll
+                    for (int off = 16; off < 64; off <<= 1) {
+                        const float ob = __shfl_xor(best, off, 64);
+                        const int oj = __shfl_xor(bj, off, 64);
+                        if (ob > best || (ob == best && oj < bj)) best = ob, bj = oj;
+                    }
+                    if (p < a.npix && h == 0) {
+                        dec.cconf[ci] = 1.f / (1.f + expf(-best));
+                        dec.ccls[ci] = bj;
+                    }
                 }
             }
         }
@@ -1006,7 +1067,7 @@ __global__ void decode_kernel(Level l0, Level l1, Level l2, int A, int B, float*
         for (int j = 0; j < REG_MAX; ++j) mx = fmaxf(mx, bx[s * REG_MAX + j]);
         float sum = 0.f, ex = 0.f;
         for (int j = 0; j < REG_MAX; ++j) {
-            const float e = expf(bx[s * REG_MAX + j] - mx);
+            const float e = __expf(bx[s * REG_MAX + j] - mx);       // v_exp_f32: arguments in [-|range of the logits|, 0], 1 ulp is far inside the 0.05 px the boxes are held to
             sum += e, ex += e * (float)j;
         }
         d[s] = ex / sum;
@@ -1194,8 +1255,9 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
-    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; };   // lane 1: internal side stream;
-    // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch
+    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; };   // lane 1: internal side stream;
+    // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch; dec 1 / 2: the head's last box /
+    // class convolution of level dec_level (its epilogue can do the decode)
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // deferred tail (throughput mode): decode + sort + NMS of forward k run on their own stream beside the convolutions
@@ -1204,14 +1266,15 @@ struct Yolo {
     hipStream_t tail = nullptr;
     hipEvent_t ev_heads = nullptr, ev_decoded = nullptr, ev_tail = nullptr;
     bool defer_tail = false, tail_pending = false;
+    bool keep_logits = false;            // test hook: also write the float32 head logits and run decode_kernel on them
     int head_begin = -1;                 // first op of the head (everything before it is one dependency chain)
     std::vector<Op> ops;
     std::vector<void*> allocs;
     float* head_box[3] = {nullptr, nullptr, nullptr};
     float* head_cls[3] = {nullptr, nullptr, nullptr};
     int lvH[3], lvW[3];
-    float *cbox = nullptr, *cconf = nullptr, *sbox = nullptr;
-    int *ccls = nullptr, *sidx = nullptr, *scount = nullptr;
+    float *cbox = nullptr, *cconf = nullptr, *sbox = nullptr, *dbg_cbox = nullptr, *dbg_cconf = nullptr;
+    int *ccls = nullptr, *sidx = nullptr, *scount = nullptr, *dbg_ccls = nullptr;
     unsigned long long* mask = nullptr;
     const float* wsrc = nullptr;
     size_t wpos = 0, wtotal = 0;
@@ -1360,12 +1423,28 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
         // measured per layer (profiles/r01_yolo_b64_*): the LDS kernel wins for stride-1 3x3 (any cin >= 16, the tail of
         // a partial 32-channel chunk is zero-filled) and for 1x1 with whole chunks; stride 2 and the rest stay direct
         const bool lds_ok = a.stride == 1 && ((a.ksz == 3 && a.cin >= 16 && a.cin % 8 == 0) || (a.ksz == 1 && a.cin % LT_CK == 0));
-        // the head's last class convolution (80 -> 80, float32 logits out): two whole steps + a 16-channel tail
-        if (a.ksz == 1 && a.stride == 1 && a.cin == 80 && a.cout == 80 && op.mt == 5 && !a.res && !force_direct && !getenv("AVHOT_CONV_NO_1X1")) {
+        DecArgs dec{};
+        if (op.dec) {
+            int aoff = 0;
+            for (int i = 0; i < op.dec_level; ++i) aoff += y.lvH[i] * y.lvW[i];
+            dec = DecArgs{y.cbox, y.cconf, y.ccls, y.A, aoff, 8 << op.dec_level, y.keep_logits ? 1 : 0};
+        }
+        // the head's last convolutions, with the decode in their epilogue: box 64 -> 64 (two whole steps), class 80 -> 80 (two
+        // whole steps + a 16-channel tail); float32 logits only on request
+        if (op.dec == 1 && a.cin == 64 && a.cout == 64 && op.mt == 4 && !force_direct) {
+            const size_t lds = (((size_t)64 * ws_stride(128) + 15) & ~size_t(15)) + (size_t)4 * 16 * DEC_ROW * sizeof(float);
+            const int n_tiles = (a.npix + 31) / 32;
+            hipLaunchKernelGGL((conv1x1_ws_kernel<4, 2, false, 1>), dim3((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024))), dim3(256), lds,
+                               st, a, n_tiles, dec);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
+        if (a.ksz == 1 && a.stride == 1 && a.cin == 80 && a.cout == 80 && op.mt == 5 && !a.res && !force_direct) {
             const size_t lds = (size_t)80 * ws_stride(160);
             const int n_tiles = (a.npix + 31) / 32;
-            hipLaunchKernelGGL((conv1x1_ws_kernel<5, 2, true>), dim3((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024))), dim3(256), lds, st,
-                               a, n_tiles);
+            const dim3 g((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024)));
+            if (op.dec == 2) hipLaunchKernelGGL((conv1x1_ws_kernel<5, 2, true, 2>), g, dim3(256), lds, st, a, n_tiles, dec);
+            else hipLaunchKernelGGL((conv1x1_ws_kernel<5, 2, true>), g, dim3(256), lds, st, a, n_tiles, dec);
             AV_LAUNCH_CHECK();
             return AV_OK;
         }
@@ -1382,7 +1461,7 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
                 const int n_tiles = (a.npix + 31) / 32, gy = a.cout / (16 * op.mt);
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
                 const dim3 g1((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 256 * per_cu / gy)), gy);
-#define AV_C1(MTV, KSV) hipLaunchKernelGGL((conv1x1_ws_kernel<MTV, KSV>), g1, dim3(256), lds, st, a, n_tiles)
+#define AV_C1(MTV, KSV) hipLaunchKernelGGL((conv1x1_ws_kernel<MTV, KSV>), g1, dim3(256), lds, st, a, n_tiles, dec)
 #define AV_C1K(MTV)                                                                                                                \
     switch (ks) {                                                                                                                  \
     case 1: AV_C1(MTV, 1); break;                                                                                              \
@@ -1592,10 +1671,12 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         CV(Slice{pl[i], 0, pc[i]}, Slice{ba, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{ba, 0, 64}, Slice{bb, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{bb, 0, 64}, Slice{-1, 0, 64}, 1, 1, false, y.head_box[i], 64, nullptr);
+        if (ok) y.ops.back().dec = 1, y.ops.back().dec_level = i;
         const size_t cls_first = y.ops.size();
         CV(Slice{pl[i], 0, pc[i]}, Slice{ca, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{ca, 0, NC}, Slice{cb, 0, NC}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{cb, 0, NC}, Slice{-1, 0, NC}, 1, 1, false, y.head_cls[i], NC, nullptr);
+        if (ok) y.ops.back().dec = 2, y.ops.back().dec_level = i;
         for (size_t q = cls_first; q < y.ops.size(); ++q) y.ops[q].lane = 1;       // own buffers, independent of the box branch
         y.A += hh * ww;
     }
@@ -1664,6 +1745,17 @@ int av_yolo_tensor(const av_yolo* h, int id, void** ptr, int* H, int* W, int* C,
         *H = h->y.lvH[i], *W = h->y.lvW[i], *C = (id & 1) ? NC : 64, *cstride = *C, *coff = 0;
         return AV_OK;
     }
+    if (id >= 110 && id < 113) {            // candidates written by the head's decode epilogues: box [A][4], confidence [A], class [A] (int32)
+        *ptr = id == 110 ? (void*)h->y.cbox : (id == 111 ? (void*)h->y.cconf : (void*)h->y.ccls);
+        *H = 1, *W = h->y.A, *C = id == 110 ? 4 : 1, *cstride = *C, *coff = 0;
+        return AV_OK;
+    }
+    if (id >= 120 && id < 123) {            // the same from decode_kernel on the kept logits (av_yolo_keep_logits)
+        AV_REQUIRE(h->y.dbg_cbox, AV_EINVAL, "av_yolo_tensor: candidates of the stand-alone decode exist only after av_yolo_keep_logits(h, 1)");
+        *ptr = id == 120 ? (void*)h->y.dbg_cbox : (id == 121 ? (void*)h->y.dbg_cconf : (void*)h->y.dbg_ccls);
+        *H = 1, *W = h->y.A, *C = id == 120 ? 4 : 1, *cstride = *C, *coff = 0;
+        return AV_OK;
+    }
     for (const auto& kv : h->y.named)
         if (kv.first == id) {
             const Buf& b = h->y.bufs[kv.second.buf];
@@ -1701,8 +1793,8 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     // so the groups only queue behind each other; dropped)
     for (size_t oi = 0; oi < y.ops.size(); ++oi) {
         const Yolo::Op& op = y.ops[oi];
-        if ((int)oi == y.head_begin && y.tail_pending)     // the previous forward's decode must have read the logits the head rewrites
-            AV_HIP(hipStreamWaitEvent(st_main, y.ev_decoded, 0));
+        if ((int)oi == y.head_begin && y.tail_pending)     // the previous forward's sort + NMS must be done with the candidates the head rewrites
+            AV_HIP(hipStreamWaitEvent(st_main, y.ev_tail, 0));
         if (y.side && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
             AV_HIP(hipEventRecord(y.ev_fork, st_main));
             AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
@@ -1742,10 +1834,13 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         lv[i] = Level{y.head_box[i], y.head_cls[i], y.lvH[i], y.lvW[i], strides[i], aoff};
         aoff += y.lvH[i] * y.lvW[i];
     }
-    hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.cbox, y.cconf,
-                       y.ccls);
-    AV_LAUNCH_CHECK();
-    if (y.defer_tail) AV_HIP(hipEventRecord(y.ev_decoded, st));
+    // The candidates (cbox / cconf / ccls) were written by the head's last convolutions.  With keep_logits the stand-alone
+    // decode runs as well, from the float32 logits into buffers of its own: the test hook that shows the two are equal.
+    if (y.keep_logits) {
+        hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.dbg_cbox,
+                           y.dbg_cconf, y.dbg_ccls);
+        AV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, st, y.A, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
     AV_LAUNCH_CHECK();
     // gain/pad of ultralytics scale_boxes
@@ -1759,6 +1854,20 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         AV_HIP(hipEventRecord(y.ev_tail, st));
         y.tail_pending = true;
     }
+    return AV_OK;
+}
+
+int av_yolo_keep_logits(av_yolo* h, int enable) {
+    AV_REQUIRE(h, AV_EINVAL, "av_yolo_keep_logits: null handle");
+    Yolo& y = h->y;
+    if (enable && !y.dbg_cbox) {
+        const size_t n = (size_t)y.B * y.A;
+        if (!dev_alloc(y, (void**)&y.dbg_cbox, n * 16) || !dev_alloc(y, (void**)&y.dbg_cconf, n * 4) || !dev_alloc(y, (void**)&y.dbg_ccls, n * 4)) {
+            av_set_error("av_yolo_keep_logits: device allocation failed");
+            return AV_ENOMEM;
+        }
+    }
+    y.keep_logits = enable != 0;
     return AV_OK;
 }
 

@@ -77,8 +77,11 @@ def load_params(model_path):
 
 
 class YoloV8n:
-    def __init__(self, model_path="random", device=0, batch=1):
+    def __init__(self, model_path="random", device=0, batch=1, keep_logits=False):
+        """keep_logits: test hook -- the head also writes its float32 logits (tensor ids 100-105) and the stand-alone decode
+        runs on them (ids 120-122); normally the decode happens in the head's last convolutions and no logits exist."""
         self._dev = Dev(device)
+        self.keep_logits = keep_logits
         self.params = load_params(model_path)
         n = int(self._dev.lib.av_yolo_param_count())
         if self.params.size != n:
@@ -99,6 +102,8 @@ class YoloV8n:
                                        self.params.size, C.byref(hd)))
         self._h = hd
         self._shape = (h, w)
+        if self.keep_logits:
+            nat.check(d.lib.av_yolo_keep_logits(hd, 1))
         B = self.batch
         self._frames = d.empty((B, h, w, 3), torch.uint8)
         self._n = d.zeros(B, torch.int32)
@@ -133,6 +138,8 @@ class YoloV8n:
         p, H, W, Cc, cs, co = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         nat.check(self._dev.lib.av_yolo_tensor(self._h, tid, C.byref(p), C.byref(H), C.byref(W), C.byref(Cc), C.byref(cs),
                                                C.byref(co)))
+        if 100 <= tid < 106 and not self.keep_logits:
+            raise RuntimeError("head logits exist only in a YoloV8n(keep_logits=True)")
         n = self.batch * H.value * W.value * cs.value
         t = torch.empty(n, dtype=torch.float32 if tid >= 100 else torch.int16, device=self._dev.device)
         nbytes = t.numel() * t.element_size()
@@ -143,6 +150,8 @@ class YoloV8n:
         arr = t.cpu().numpy().reshape(self.batch, H.value, W.value, cs.value)[..., co.value:co.value + Cc.value]
         if image is not None:
             arr = arr[image]
+        if tid in (112, 122):
+            return np.ascontiguousarray(arr).view(np.int32)
         if tid >= 100:
             return arr.astype(np.float32)
         if self.precision == "bf16":                       # (a library built with bf16 activations: comparison runs only)

@@ -19,7 +19,7 @@ def setup():
     net = R.build_model(params)
     with torch.no_grad():
         feats = net.features(torch.from_numpy(R.preprocess(frame))[None])
-    model = Y.YoloV8n("random:0")
+    model = Y.YoloV8n("random:0", keep_logits=True)      # the logit-level tests need the float32 head outputs
     got = model.detect(frame)
     return Y, R, frame, feats, model, got
 
@@ -58,7 +58,7 @@ def test_feature_maps_at_a_resolution_with_partial_tiles(setup):
     net = R.build_model(R.random_params(0))
     with torch.no_grad():
         f = net.features(torch.from_numpy(R.preprocess(fr))[None])
-    m = Y.YoloV8n("random:0")
+    m = Y.YoloV8n("random:0", keep_logits=True)
     m.detect(fr)
     assert m.dims()[:2] == (480, 640)
     for tid, key in ((1, "l1"), (2, "l2"), (4, "l4"), (6, "l6"), (8, "l8"), (9, "l9"), (12, "l12"), (15, "p3"), (18, "p4"), (21, "p5")):
@@ -141,6 +141,7 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
     net = R.build_model(params)
     det = ObjectDetector(mode="yolo", model_path=path)
     assert det.mode == "yolo"
+    probe = Y.YoloV8n(path, keep_logits=True)          # same network with the float32 logits kept: measures the logit error
 
     def post(head):
         xyxy, conf, cls = R.decode(head)
@@ -156,8 +157,10 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
         class_path.append((gb, gk))
         # the device's logit error on this frame (the only way the network's arithmetic enters the post-processing)
         eb = ec = 0.0
+        pb_, pc_, pk_ = probe.detect(fr)
+        assert np.array_equal(np.trunc(pb_), gb) and np.array_equal(pk_, gk)       # the production path decodes in the head's epilogue: same detections
         for i, (b, c) in enumerate(f["head"]):
-            hb, hc = det.model.tensor(100 + 2 * i), det.model.tensor(101 + 2 * i)
+            hb, hc = probe.tensor(100 + 2 * i), probe.tensor(101 + 2 * i)
             eb = max(eb, float(np.abs(hb - b[0].numpy().transpose(1, 2, 0)).max()))
             ec = max(ec, float(np.abs(hc - c[0].numpy().transpose(1, 2, 0)).max()))
             assert np.abs(hb - b[0].numpy().transpose(1, 2, 0)).max() < 0.001 * float(b.abs().max()) + 1e-6
@@ -199,8 +202,9 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
         gb, gk = class_path[b % len(frames)]
         assert n[b] == len(gb) and np.array_equal(np.trunc(box[b, :n[b]]), gb) and np.array_equal(cls[b, :n[b]], gk), b
     batched.close()
+    probe.close()
     # per-anchor candidates under the spread parameters
-    msp = Y.YoloV8n(path)
+    msp = Y.YoloV8n(path, keep_logits=True)
     for fr in frames[:3]:
         st = candidate_stats(msp, fr, R, net, torch)
         assert st["box_max_px"] < 0.05 and st["conf_max"] < 2e-3 and st["class_flips"] <= 10, st
@@ -239,6 +243,37 @@ def test_fused_c2f_block_is_bit_identical_to_its_four_launches(setup, monkeypatc
     assert fused.shape == (len(frames), 96, 160, 32) and fused.any()
     assert np.array_equal(fused.view(np.uint32), unfused.view(np.uint32)), int((fused != unfused).sum())
     m.close()
+
+
+def test_fused_decode_equals_decode_kernel(setup):
+    """The head's last convolutions decode in their epilogue (DFL expectation per lane group, first-maximum class across
+    lane groups); decode_kernel does the same from the float32 logits.  With keep_logits both run: every anchor's box,
+    confidence and class must be equal bit for bit, for a batch whose frames differ, and a model without kept logits (the
+    production path: no logits written at all) must return the same detections."""
+    import torch
+    Y, R, frame, feats, model, _ = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame, synthetic_frame(720, 1280, 6, 40), np.full((720, 1280, 3), 200, np.uint8), synthetic_frame(720, 1280, 2, 77)]
+    out = {}
+    for keep in (True, False):
+        m = Y.YoloV8n("random:0", batch=len(frames), keep_logits=keep)
+        m._prepare(720, 1280)
+        m._frames.copy_(torch.as_tensor(np.stack(frames)))
+        m.forward_device(m._frames)
+        torch.cuda.synchronize()
+        out[keep] = (m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(), m._conf.cpu().numpy().copy(), m._cls.cpu().numpy().copy())
+        if keep:
+            for a_id, b_id in ((110, 120), (111, 121), (112, 122)):
+                a, b = m.tensor(a_id, image=None), m.tensor(b_id, image=None)
+                assert a.shape == b.shape and a.shape[0] == len(frames) and a.shape[2] == 5040
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (a_id, int((a != b).sum()))
+            assert np.isfinite(m.tensor(110, image=None)).all() and (m.tensor(111, image=None) > 0).all()
+        m.close()
+    n = out[True][0]
+    assert np.array_equal(n, out[False][0]) and n.min() > 0
+    for b in range(len(frames)):
+        for k in (1, 2, 3):
+            assert np.array_equal(out[True][k][b, :n[b]], out[False][k][b, :n[b]]), (b, k)
 
 
 def test_object_detector_yolo_mode(setup):

@@ -34,7 +34,7 @@ if a.model == "spread":
 else:
     params, path = R.random_params(int(a.model.split(":")[1])), a.model
 net = R.build_model(params)
-model = Y.YoloV8n(path)
+model = Y.YoloV8n(path, keep_logits=True)
 if a.precision:
     model.precision = a.precision
 print("== candidates (5040 anchors per frame), model %s, precision %s" % (a.model, model.precision))

@@ -31,7 +31,34 @@ def serial_all():
 def lanes_after_yolo_side():
     # lane chain of frame k on the side stream, forked AFTER frame k's detector has been enqueued on the main stream's fork point
     loop.enqueue_generate(); nat.check(L.av_fork(loop.ctx.handle, s)); loop.enqueue_detect(); loop.enqueue_lanes(side); nat.check(L.av_join(loop.ctx.handle, s))
+# Hough(k-1) on a third stream from the very start of the step (beside generate / preprocess / stem / the lane pixel stages,
+# none of which needs much LDS), pixel stages of frame k into a second workspace
+import ctypes as C
+hs = torch.cuda.Stream(device=loop.dev)
+hsp = C.c_void_p(hs.cuda_stream)
+ws2 = [loop.ws, torch.empty_like(loop.ws)]
+nat.check(L.av_lane_workspace_init(loop.ctx.handle, s, loop.S, loop.h, loop.w, loop.ms, nat.ptr(ws2[1])))
+loop.synchronize()
+state = {"k": 0, "pending": False}
+def third_stream():
+    k = state["k"]
+    if state["pending"]:
+        hs.wait_stream(loop.stream)
+        loop.ws = ws2[(k - 1) % 2]
+        loop.enqueue_lanes(hsp, stages=16)
+    loop.enqueue_generate()
+    nat.check(L.av_fork(loop.ctx.handle, s))
+    loop.ws = ws2[k % 2]
+    loop.enqueue_lanes(side, stages=2)
+    loop.enqueue_detect()
+    nat.check(L.av_join(loop.ctx.handle, s))
+    loop.stream.wait_stream(hs)
+    state["k"] = k + 1; state["pending"] = True
+def third_flush():
+    hs.wait_stream(loop.stream); loop.ws = ws2[(state["k"] - 1) % 2]; loop.enqueue_lanes(hsp, stages=16); loop.stream.wait_stream(hs); state["pending"] = False
+    loop.join_detector_tail()
 run("generate + yolo (tail deferred)", yolo_only, loop.join_detector_tail)
+run("Hough(k-1) on a third stream from the step start, two workspaces", third_stream, third_flush)
 run("+ lane pixel stages on the side stream", yolo_pixels_side, loop.join_detector_tail)
 run("+ lane Hough+fit (of the previous points) on the side stream", yolo_hough_side, loop.join_detector_tail)
 run("bench default: step_deferred (Hough(k-1), pixels(k) beside yolo(k))", loop.step_deferred, loop.flush_lanes)
