@@ -540,25 +540,28 @@ struct DecArgs { float* cbox; float* cconf; int* ccls; int A, aoff, stride, keep
 constexpr int DEC_ROW = 68;                        // floats per pixel row of the box detour (64 + 4: conflict-free b128 rows)
 
 template <int MT, int KS, bool TAIL16 = false, int DEC = 0>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), via the K = 16 MFMA
-__global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles, DecArgs dec) {
+__global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvArgs a, int n_tiles, DecArgs dec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     constexpr int NT = 2, cin = KS * 32 + (TAIL16 ? 16 : 0), wrowb = ws_stride(cin * 2), parts = cin >> 3;
+    // waves per workgroup: two for the box decode, whose per-wave LDS detour would otherwise push the workgroup past the 19 KB
+    // that stay free on a CU beside the other head lane's 144-KB 3x3 kernel
+    constexpr int NWV = DEC == 1 ? 2 : 4, NTH = NWV * 64;
     static_assert(DEC == 0 || (DEC == 1 && MT == 4) || (DEC == 2 && MT == 5), "decode epilogues belong to the 64- and 80-channel head outputs");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     const int ch_base = blockIdx.y * 16 * MT;
     {
-        constexpr int WP = 16 * MT * parts, WB = WP >= 2048 ? 8 : (WP + 255) / 256;
-        for (int i0 = 0; i0 < WP; i0 += 256 * WB) {
+        constexpr int WP = 16 * MT * parts, WB = WP >= 8 * NTH ? 8 : (WP + NTH - 1) / NTH;
+        for (int i0 = 0; i0 < WP; i0 += NTH * WB) {
             uint4 wv[WB];
 #pragma unroll
             for (int k = 0; k < WB; ++k) {
-                const int i = i0 + k * 256 + tid, row = i / parts, part = i - row * parts;
+                const int i = i0 + k * NTH + tid, row = i / parts, part = i - row * parts;
                 wv[k] = make_uint4(0, 0, 0, 0);
                 if (i < WP) wv[k] = *reinterpret_cast<const uint4*>(a.wgt + (size_t)(ch_base + row) * a.kpad + part * 8);
             }
 #pragma unroll
             for (int k = 0; k < WB; ++k) {
-                const int i = i0 + k * 256 + tid, row = i / parts, part = i - row * parts;
+                const int i = i0 + k * NTH + tid, row = i / parts, part = i - row * parts;
                 if (i < WP) *reinterpret_cast<uint4*>(lsm + (size_t)row * wrowb + part * 16) = wv[k];
             }
         }
@@ -571,8 +574,8 @@ __global__ void __launch_bounds__(256) conv1x1_ws_kernel(ConvArgs a, int n_tiles
     __syncthreads();
     const unsigned char* arow = lsm + (size_t)l15 * wrowb + 16 * h;
     // a wave's tile: pixels 32 t .. 32 t + 31 (fragment nt: pixels 32 t + 16 nt + l15); tiles strided over all waves of the grid
-    const int wstride = gridDim.x * 4;
-    for (int t = blockIdx.x * 4 + wave; t < n_tiles; t += wstride) {
+    const int wstride = gridDim.x * NWV;
+    for (int t = blockIdx.x * NWV + wave; t < n_tiles; t += wstride) {
         half8 B[KS][NT];
         half4 Bt[NT];
         long pix[NT];
@@ -1432,9 +1435,9 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
         // the head's last convolutions, with the decode in their epilogue: box 64 -> 64 (two whole steps), class 80 -> 80 (two
         // whole steps + a 16-channel tail); float32 logits only on request
         if (op.dec == 1 && a.cin == 64 && a.cout == 64 && op.mt == 4 && !force_direct) {
-            const size_t lds = (((size_t)64 * ws_stride(128) + 15) & ~size_t(15)) + (size_t)4 * 16 * DEC_ROW * sizeof(float);
+            const size_t lds = (((size_t)64 * ws_stride(128) + 15) & ~size_t(15)) + (size_t)2 * 16 * DEC_ROW * sizeof(float);
             const int n_tiles = (a.npix + 31) / 32;
-            hipLaunchKernelGGL((conv1x1_ws_kernel<4, 2, false, 1>), dim3((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024))), dim3(256), lds,
+            hipLaunchKernelGGL((conv1x1_ws_kernel<4, 2, false, 1>), dim3((unsigned)std::max(1, std::min((n_tiles + 1) / 2, 2048))), dim3(128), lds,
                                st, a, n_tiles, dec);
             AV_LAUNCH_CHECK();
             return AV_OK;
