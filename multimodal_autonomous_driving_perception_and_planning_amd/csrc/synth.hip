@@ -109,26 +109,38 @@ __global__ void __launch_bounds__(256) synth_rows_kernel(int h, int w, int strea
     unsigned pk[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) pk[q] = 0;
+    bool any_box = false;                       // most rows cross no vehicle box: the six range tests per pixel are skipped there
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int x = g * 16 + j;
-        int c0, c1, c2;
-        if (sky) {
-            c0 = sc0, c1 = sc1, c2 = sc2;
-        } else {
-            unsigned hsh = ((unsigned)x * 73856093u) ^ K;
-            hsh = (hsh ^ (hsh >> 13)) * 1274126177u;
-            const int tex = (int)((hsh >> 24) & 15u);
-            c0 = 84 + tex + 4, c1 = 84 + tex + 2, c2 = 84 + tex;
-            if (half >= 0 && (abs(x - xc0) <= half || abs(x - xc1) <= half)) c0 = c1 = c2 = 235;
+    for (int v = 0; v < 6; ++v) any_box = any_box || bx1[v] > bx0[v];
+    if (sky && !any_box) {                      // a sky row is one colour: 16 pixels = the 3-byte pattern repeated, no per-pixel work
+        const unsigned t = (unsigned)sc0 | ((unsigned)sc1 << 8) | ((unsigned)sc2 << 16);
+        const unsigned w0 = t | (t << 24), w1 = (t >> 8) | (t << 16), w2 = (t >> 16) | (t << 8);
+#pragma unroll
+        for (int q = 0; q < 12; q += 3) pk[q] = w0, pk[q + 1] = w1, pk[q + 2] = w2;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int x = g * 16 + j;
+            int c0, c1, c2;
+            if (sky) {
+                c0 = sc0, c1 = sc1, c2 = sc2;
+            } else {
+                unsigned hsh = ((unsigned)x * 73856093u) ^ K;
+                hsh = (hsh ^ (hsh >> 13)) * 1274126177u;
+                const int tex = (int)((hsh >> 24) & 15u);
+                c0 = 84 + tex + 4, c1 = 84 + tex + 2, c2 = 84 + tex;
+                if (half >= 0 && (abs(x - xc0) <= half || abs(x - xc1) <= half)) c0 = c1 = c2 = 235;
+            }
+            if (any_box) {
+#pragma unroll
+                for (int v = 0; v < 6; ++v)
+                    if (x >= bx0[v] && x < bx1[v]) c0 = sbox[v][4], c1 = sbox[v][5], c2 = sbox[v][6];
+            }
+            const int b = j * 3;
+            pk[b >> 2] |= (unsigned)c0 << (8 * (b & 3));
+            pk[(b + 1) >> 2] |= (unsigned)c1 << (8 * ((b + 1) & 3));
+            pk[(b + 2) >> 2] |= (unsigned)c2 << (8 * ((b + 2) & 3));
         }
-#pragma unroll
-        for (int v = 0; v < 6; ++v)
-            if (x >= bx0[v] && x < bx1[v]) c0 = sbox[v][4], c1 = sbox[v][5], c2 = sbox[v][6];
-        const int b = j * 3;
-        pk[b >> 2] |= (unsigned)c0 << (8 * (b & 3));
-        pk[(b + 1) >> 2] |= (unsigned)c1 << (8 * ((b + 1) & 3));
-        pk[(b + 2) >> 2] |= (unsigned)c2 << (8 * ((b + 2) & 3));
     }
     uint4* o = reinterpret_cast<uint4*>(out + (((size_t)s * h + y) * w + (size_t)g * 16) * 3);
     o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
