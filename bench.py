@@ -411,7 +411,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     pix_bytes = loop.lane_pixel_bytes_per_px * px
     ks = [
         {"kernel": "yolo forward: preprocess + stem + fused C2f (layer 2) + 58 conv launches (conv3x3_ws_kernel / "
-                   "conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel) + sppf + upsample + decode + sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
+                   "conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel; decode in the head's last convolutions) + sppf + upsample + "
+                   "sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
          "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
         {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",
