@@ -282,7 +282,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
  * confidence filter -> class-aware NMS -> boxes scaled back to the frame.  `weights` is a HOST array in
  * the parameter order documented in perception/yolo.py (per conv: weight[cout][cin][k][k], then BN
  * gamma, beta, running_mean, running_var or, for the two plain Conv2d of each head branch, bias);
- * BatchNorm is folded and everything is converted to bf16 at creation.  All activation and NMS scratch
+ * BatchNorm is folded and everything is converted to IEEE half at creation (float32 accumulation).  All activation and NMS scratch
  * is allocated here, once. */
 typedef struct av_yolo av_yolo;
 size_t av_yolo_param_count(void);
