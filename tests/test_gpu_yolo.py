@@ -166,24 +166,25 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
             assert np.abs(hb - b[0].numpy().transpose(1, 2, 0)).max() < 0.001 * float(b.abs().max()) + 1e-6
             assert np.abs(hc - c[0].numpy().transpose(1, 2, 0)).max() < 0.001 * float(c.abs().max()) + 1e-6
         # what perturbations of that size do to the oracle's own selection
-        chaos = []
+        chaos, dcount = [], []
         for trial in range(8):
             hd = [(b + torch.from_numpy(rs.uniform(-eb, eb, tuple(b.shape)).astype(np.float32)),
                    c + torch.from_numpy(rs.uniform(-ec, ec, tuple(c.shape)).astype(np.float32))) for b, c in f["head"]]
             pb, pc, pk = post(hd)
             _, miss, extra, _ = match_detections(pb, pk, np.trunc(wb), wk, 1.0)
             chaos.append((len(miss) + len(extra)) / max(1, len(pb) + len(wb)))
+            dcount.append(abs(len(pb) - len(wb)))
         pairs, miss, extra, worst = match_detections(np.trunc(gb), gk, np.trunc(wb), wk, 1.0)
         rate = (len(miss) + len(extra)) / max(1, len(gb) + len(wb))
         dconf = max([abs(float(gc[j]) - float(wc[i])) for i, j in pairs], default=0.0)
         per_frame.append(dict(frame=k, n_want=len(wb), n_got=len(gb), matched=len(pairs), flip_rate=round(rate, 3),
-                              oracle_self_flip_max=round(max(chaos), 3), oracle_self_flip_mean=round(float(np.mean(chaos)), 3),
+                              oracle_self_flip_max=round(max(chaos), 3), oracle_self_flip_mean=round(float(np.mean(chaos)), 3), oracle_self_dcount=max(dcount),
                               eps_box=eb, eps_cls=ec, worst_px=worst, worst_dconf=dconf))
     for r in per_frame:
         print("spread frame %(frame)d: %(n_want)d/%(n_got)d boxes, %(matched)d matched, flip rate %(flip_rate).3f "
               "(oracle under +-eps noise: max %(oracle_self_flip_max).3f mean %(oracle_self_flip_mean).3f), logit error box %(eps_box).2g "
               "cls %(eps_cls).2g, worst %(worst_px).1f px / %(worst_dconf).1e conf" % r)
-        assert abs(r["n_got"] - r["n_want"]) <= max(3, 0.1 * r["n_want"]), r
+        assert abs(r["n_got"] - r["n_want"]) <= r["oracle_self_dcount"] + 3, r       # the kept count moves with the cascade too
         assert r["flip_rate"] <= r["oracle_self_flip_max"] + 0.05, r
         assert r["worst_px"] <= 1.0, r
         if r["flip_rate"] == 0:          # (after a flip, a pair within 1 px may be two different anchors: their confidences are held per anchor below)
