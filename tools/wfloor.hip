@@ -1,0 +1,109 @@
+// What is the ~15-us floor of a mid-network convolution launch made of?  (Not part of the library.)
+// Chains of back-to-back launches on one stream, each 256 workgroups x 512 threads with 104 KB of dynamic LDS like
+// conv3x3_ws_kernel<4,1,8,64> at P4 (64 -> 64 channels, 24x40 maps, 64 images: 576 tiles, 2.25 per workgroup):
+//   A  empty kernel                                   -> launch + dispatch + drain of a chip-wide, LDS-heavy grid
+//   B  + every workgroup copies the same 76 KB (the weights) from global memory into LDS
+//   C  + per tile: a 26-KB patch global -> registers -> LDS, two barriers (2.25 tiles per workgroup)
+//   D  + per tile: 72 MFMAs per wave out of LDS (18 steps x 4)
+//   E  + per tile: epilogue (bias, SiLU, half stores of 8 x 16 x 64 outputs)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WROW = 1184, PIXB = 160, NPIX = 10 * 18, WBYTES = 64 * WROW, LDS = WBYTES + NPIX * PIXB;
+
+template <int LEVEL>
+__global__ void __launch_bounds__(512) floor_kernel(const uint4* __restrict__ wgt, const uint4* __restrict__ in, _Float16* __restrict__ out,
+                                                    int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    if (LEVEL >= 1) {
+        for (int i0 = 0; i0 < WBYTES / 16; i0 += 512 * 5) {
+            uint4 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const int i = i0 + k * 512 + tid; v[k] = i < WBYTES / 16 ? wgt[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const int i = i0 + k * 512 + tid; if (i < WBYTES / 16) reinterpret_cast<uint4*>(lsm)[i] = v[k]; }
+        }
+        __syncthreads();
+    }
+    if (LEVEL >= 2) {
+        unsigned char* patch = lsm + WBYTES;
+        float keep = 0.f;
+        for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            uint4 pv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + k * 512;                                  // 180 pixels x 8 pieces = 1440
+                pv[k] = i < NPIX * 8 ? in[(size_t)t * NPIX * 8 + i] : make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + k * 512;
+                if (i < NPIX * 8) *reinterpret_cast<uint4*>(patch + (i >> 3) * PIXB + (i & 7) * 16) = pv[k];
+            }
+            __syncthreads();
+            f32x4 acc[4];
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (LEVEL >= 3) {
+#pragma unroll
+                for (int st = 0; st < 18; ++st) {
+                    const int c0 = (st / 9) * 32, tap = st % 9, ky = tap / 3, kx = tap % 3;
+                    const half8 b = *reinterpret_cast<const half8*>(patch + ((wave + ky) * 18 + l15 + kx) * PIXB + c0 * 2 + 16 * h);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const half8 a = *reinterpret_cast<const half8*>(lsm + (m * 16 + l15) * WROW + (tap * 64 + c0) * 2 + 16 * h);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+            if (LEVEL >= 4) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    _Float16 o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float v = acc[m][q] + 0.1f; o[q] = (_Float16)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v))); }
+                    *reinterpret_cast<uint2*>(out + ((size_t)t * 128 + wave * 16 + l15) * 64 + m * 16 + 4 * h) = *reinterpret_cast<uint2*>(o);
+                }
+            } else {
+                for (int m = 0; m < 4; ++m) keep += acc[m][0];
+            }
+        }
+        if (keep == 12345.f) out[0] = (_Float16)keep;
+    }
+}
+
+int main() {
+    const int n_tiles = 576, G = 256, CHAIN = 40;
+    uint4 *wgt, *in; _Float16* out;
+    CK(hipMalloc(&wgt, WBYTES)); CK(hipMalloc(&in, (size_t)n_tiles * NPIX * 128)); CK(hipMalloc(&out, (size_t)n_tiles * 128 * 64 * 2));
+    CK(hipMemset(wgt, 0, WBYTES)); CK(hipMemset(in, 0, (size_t)n_tiles * NPIX * 128));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    auto run = [&](const char* name, auto launch) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipEventRecord(a));
+            for (int i = 0; i < CHAIN; ++i) launch();
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); if (rep && ms < best) best = ms;
+        }
+        CK(hipGetLastError());
+        printf("%-78s %6.2f us per launch\n", name, best * 1e3 / CHAIN); fflush(stdout);
+    };
+#define SETUP(L) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(floor_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64))
+    SETUP(0); SETUP(1); SETUP(2); SETUP(3); SETUP(4);
+    run("A  empty, 256 x 512 threads, 104 KB LDS", [&] { hipLaunchKernelGGL(floor_kernel<0>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    run("A' empty, 256 x 512 threads, no LDS", [&] { hipLaunchKernelGGL(floor_kernel<0>, dim3(G), dim3(512), 0, 0, wgt, in, out, n_tiles); });
+    run("A\" empty, 1024 x 256 threads, no LDS", [&] { hipLaunchKernelGGL(floor_kernel<0>, dim3(1024), dim3(256), 0, 0, wgt, in, out, n_tiles); });
+    run("B  + 76 KB of weights into LDS per workgroup", [&] { hipLaunchKernelGGL(floor_kernel<1>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    run("C  + 2.25 tiles: patch global -> LDS, two barriers each", [&] { hipLaunchKernelGGL(floor_kernel<2>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    run("D  + 72 MFMAs per wave and tile out of LDS", [&] { hipLaunchKernelGGL(floor_kernel<3>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    run("E  + epilogue (SiLU, half stores)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    run("E  with 1 tile per workgroup (256 tiles)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(G), dim3(512), LDS, 0, wgt, in, out, 256); });
+    run("E  on 128 workgroups (4.5 tiles each)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(128), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    return 0;
+}
