@@ -308,7 +308,8 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                "why": "one workgroup per stream walks its frames in order (frame t+1 needs frame t's table)",
                "cus_occupied": min(S, N_CUS), "us_per_frame_per_stream": round(t_trk * 1e3 / W, 3),
                "bytes_per_launch": TRACKER_BYTES * F, "achieved": hbm(TRACKER_BYTES * F, t_trk), "peak": HBM_PEAK_GBS,
-               "unit": "GB/s", "frac": round(hbm(TRACKER_BYTES * F, t_trk) / HBM_PEAK_GBS, 5)})
+               "unit": "GB/s", "frac": round(hbm(TRACKER_BYTES * F, t_trk) / HBM_PEAK_GBS, 5),
+               "traffic": pmc_traffic("tracker_pmc.json", "hbm_bytes_per_frame", F)})
     ks.append({"kernel": "planner_wave_kernel", "stage": "plan", "branch": "main", "avg_ms": t_pl,
                "bound": "hbm" if F >= 4096 else "latency", "bytes_per_launch": pb, "achieved": hbm(pb, t_pl),
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm(pb, t_pl) / HBM_PEAK_GBS, 4),

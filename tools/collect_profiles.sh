@@ -17,6 +17,8 @@ trace yolo_b64 python3 tools/ybench.py --batch 64 --reps 5
 pmc lane_fetch FETCH_SIZE python3 tools/lbench.py --reps 2
 pmc lane_write WRITE_SIZE python3 tools/lbench.py --reps 2
 pmc lane_sq "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 tools/lbench.py --reps 2
+pmc trk_fetch FETCH_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2
+pmc trk_write WRITE_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2
 pmc plan_fetch FETCH_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages plan --reps 2
 pmc plan_write WRITE_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages plan --reps 2
 pmc yolo_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python3 tools/ybench.py --batch 64 --reps 3
