@@ -106,8 +106,7 @@ class LaneDetector:
         h, w = frame.shape[:2]
         self._prepare(h, w)
         d = self._dev
-        np.copyto(self._stage.h["frame"][0], frame)
-        self._stage.upload()
+        self._stage.upload_from("frame", frame)          # host copy and DMA pipelined in four pieces
         io = self._io
         cfg = nat.LaneCfg(50, 50, 150, self.MAX_SEGMENTS, float(self.smoothing_factor))
         nat.check(d.lib.av_lane_detect(d.ctx.handle, d.stream, C.byref(cfg), 1, h, w, self._stage.ptr("frame"),
