@@ -77,6 +77,63 @@ __global__ void __launch_bounds__(512) floor_kernel(const uint4* __restrict__ wg
     }
 }
 
+// W: the same layer with 2-row x 8-column pixel blocks dealt to WAVES: the workgroup shares only the weights, every wave stages
+// its own 4 x 10-pixel patch (6.4 KB) and never meets a barrier after the weight load; 3840 blocks on 2048 waves.
+constexpr int BPIX = 40, LDSW = WBYTES + 8 * BPIX * PIXB;
+__global__ void __launch_bounds__(512) block_kernel(const uint4* __restrict__ wgt, const uint4* __restrict__ in, _Float16* __restrict__ out,
+                                                    int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    for (int i0 = 0; i0 < WBYTES / 16; i0 += 512 * 5) {
+        uint4 v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const int i = i0 + k * 512 + tid; v[k] = i < WBYTES / 16 ? wgt[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const int i = i0 + k * 512 + tid; if (i < WBYTES / 16) reinterpret_cast<uint4*>(lsm)[i] = v[k]; }
+    }
+    unsigned char* patch = lsm + WBYTES + wave * BPIX * PIXB;
+    const int nw = gridDim.x * 8;
+    int b = blockIdx.x * 8 + wave;
+    uint4 pv[5];
+    auto gload = [&](int bb) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) pv[k] = in[((size_t)bb * BPIX * 8 + lane + k * 64) % ((size_t)576 * NPIX * 8)];
+    };
+    if (b < n_blocks) gload(b);
+    __syncthreads();
+    for (; b < n_blocks; b += nw) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const int i = lane + k * 64; *reinterpret_cast<uint4*>(patch + (i >> 3) * PIXB + (i & 7) * 16) = pv[k]; }
+        if (b + nw < n_blocks) gload(b + nw);
+        f32x4 acc[4];
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* brow = patch + ((l15 >> 3) * 10 + (l15 & 7)) * PIXB + 16 * h;
+        half8 bq[2], aq[2][4];
+        auto ld = [&](int slot, int st) {
+            const int c0 = (st / 9) * 32, tap = st % 9, ky = tap / 3, kx = tap % 3;
+            bq[slot] = *reinterpret_cast<const half8*>(brow + (ky * 10 + kx) * PIXB + c0 * 2);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) aq[slot][m] = *reinterpret_cast<const half8*>(lsm + (m * 16 + l15) * WROW + (tap * 64 + c0) * 2 + 16 * h);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) ld((st + 1) & 1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[st & 1][m], bq[st & 1], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            _Float16 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float v = acc[m][q] + 0.1f; o[q] = (_Float16)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v))); }
+            *reinterpret_cast<uint2*>(out + ((size_t)b * 16 + l15) * 64 + m * 16 + 4 * h) = *reinterpret_cast<uint2*>(o);
+        }
+    }
+}
+
 int main() {
     const int n_tiles = 576, G = 256, CHAIN = 40;
     uint4 *wgt, *in; _Float16* out;
@@ -105,5 +162,7 @@ int main() {
     run("E  + epilogue (SiLU, half stores)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(G), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
     run("E  with 1 tile per workgroup (256 tiles)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(G), dim3(512), LDS, 0, wgt, in, out, 256); });
     run("E  on 128 workgroups (4.5 tiles each)", [&] { hipLaunchKernelGGL(floor_kernel<4>, dim3(128), dim3(512), LDS, 0, wgt, in, out, n_tiles); });
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    run("W  blocks of 2x8 pixels dealt to waves, no barrier after the weights", [&] { hipLaunchKernelGGL(block_kernel, dim3(G), dim3(512), LDSW, 0, wgt, in, out, 3840); });
     return 0;
 }
