@@ -199,6 +199,26 @@ __global__ void __launch_bounds__(512) mega_kernel(const uint4* __restrict__ wgt
     }
 }
 
+// P: barrier among the 4 workgroups of a "cluster" only (64 clusters = 64 images, 4 workgroups each): what a per-image fused
+// chain of layers would pay per layer instead of a launch.  Empty layers: the time is barrier cost alone.
+__global__ void __launch_bounds__(512) cluster_kernel(unsigned* ctrs, int layers) {
+    unsigned* ctr = ctrs + (blockIdx.x >> 2) * 32;                        // one 128-byte line per cluster
+    for (int layer = 0; layer < layers; ++layer) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(ctr, 1u);
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(layer + 1) * 4u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) return;
+            }
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
+
 int main() {
     const int n_tiles = 576, G = 256, CHAIN = 40;
     uint4 *wgt, *in; _Float16* out;
@@ -243,6 +263,20 @@ int main() {
         }
         CK(hipGetLastError());
         printf("%-78s %6.2f us per layer\n", "M  10 such layers in one persistent launch, grid barrier between them", best * 1e3 / LAYERS);
+    }
+    {
+        unsigned* ctrs; CK(hipMalloc(&ctrs, 64 * 128));
+        const int LAYERS = 100;
+        float best = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipMemsetAsync(ctrs, 0, 64 * 128, 0));
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(cluster_kernel, dim3(256), dim3(512), 0, 0, ctrs, LAYERS);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); if (rep && ms < best) best = ms;
+        }
+        CK(hipGetLastError());
+        printf("%-78s %6.2f us per barrier\n", "P  barrier among 4 workgroups (64 clusters side by side), empty layers", best * 1e3 / LAYERS);
     }
     return 0;
 }
