@@ -303,8 +303,8 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
 //    next tile's patch (registers) and residual loads are issued AFTER the epilogue's stores and consumed after the next
 //    tile's MFMAs;
 //  * LDS row strides = 32 mod 64 bytes (ws_stride): ds_read_b128's four 16-lane groups then touch every bank once.
-// Same K order (chunk outer, tap inner) and epilogue as conv_lds_kernel: bit-identical outputs for cin 16/32/64; cin = 80
-// runs its last 16 channels through the K = 16 MFMA instead of zero-padding the chunk.
+// Same K order (chunk outer, tap inner), zero padding and epilogue as conv_lds_kernel: bit-identical outputs, cin = 80 included
+// (tests/test_gpu_yolo.py::test_cin80_layers_equal_generic_kernels).
 // row stride of an LDS image: the bytes rounded up to = 32 mod 64 (conflict-free ds_read_b128, see conv_lds_kernel)
 constexpr int ws_stride(int bytes) { return bytes + (32 - bytes % 64 + 64) % 64; }
 
@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
     };
     const unsigned char* arow = wts + (size_t)l15 * wrowb;
     const unsigned char* brow = patch + (size_t)(NT * wave * S * PW + l15 * S) * pixb;
-    // K steps: chunk outer, tap inner (conv_lds_kernel's order); 32 channels per step, a last chunk of 16 (cin = 80) goes through
-    // the K = 16 MFMA with 8-byte operands (lane group h holds channels 4h .. 4h+3 of the chunk)
+    // K steps: chunk outer, tap inner (conv_lds_kernel's order); 32 channels per step, a last chunk of 16 (cin = 80) is a K = 32
+    // step zero-padded in registers
     constexpr int NK32 = cinp / LT_CK, NSTEP = 9 * (NK32 + (cinp % LT_CK ? 1 : 0));
     auto ld_ab = [&](half8* A, half8* B, int step) {
         const int chunk = step / 9, c0 = chunk * LT_CK, tap = step % 9, ky = tap / 3, kx = tap - ky * 3;
@@ -404,31 +404,30 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const half8*>(brow + ((nt * S + ky) * PW + kx) * pixb + c0 * 2 + 16 * h);
         } else {
+            // last chunk of 16 channels (cin = 80): a K = 32 step whose upper 16 k are zeros in BOTH operands -- lane groups 0, 1
+            // hold channels c0 + 8h .. +7, groups 2, 3 zeros (their loads repeat group h & 1's address and are discarded).  Exactly
+            // conv_lds_kernel's zero-filled partial chunk, so the two kernels stay bit-identical for cin = 80 too.  (A K = 16 MFMA
+            // accumulating onto a K = 32 MFMA's result was used here before: hipcc 7.2 inserts no wait states between the two
+            // different-length MFMAs and the second can read a stale accumulator -- DESIGN.md section 6.)
+            const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int ho = 16 * (h & 1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const half4 v = *reinterpret_cast<const half4*>(arow + mt * 16 * wrowb + (tap * cinp + c0) * 2 + 8 * h);
-                A[mt][0] = v.x, A[mt][1] = v.y, A[mt][2] = v.z, A[mt][3] = v.w;
+                const half8 v = *reinterpret_cast<const half8*>(arow + mt * 16 * wrowb + (tap * cinp + c0) * 2 + ho);
+                A[mt] = h < 2 ? v : z8;
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const half4 v = *reinterpret_cast<const half4*>(brow + ((nt * S + ky) * PW + kx) * pixb + c0 * 2 + 8 * h);
-                B[nt][0] = v.x, B[nt][1] = v.y, B[nt][2] = v.z, B[nt][3] = v.w;
+                const half8 v = *reinterpret_cast<const half8*>(brow + ((nt * S + ky) * PW + kx) * pixb + c0 * 2 + ho);
+                B[nt] = h < 2 ? v : z8;
             }
         }
     };
-    auto mma = [&](f32x4 (&acc)[MT][NT], const half8* A, const half8* B, int step) {
-        const bool k32 = step / 9 < NK32;
+    auto mma = [&](f32x4 (&acc)[MT][NT], const half8* A, const half8* B, int) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (k32) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
-                else {
-                    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-                    const h4v a4 = {A[mt][0], A[mt][1], A[mt][2], A[mt][3]}, b4 = {B[nt][0], B[nt][1], B[nt][2], B[nt][3]};
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[mt][nt], 0, 0, 0);
-                }
-            }
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
     };
     // ---- pipeline: the patch of tile t is put into LDS one iteration ahead, the loads of tile t+1 (patch -> registers) and the
     // residual of tile t are issued just before tile t's MFMAs and consumed right after them ------------------------------
@@ -539,7 +538,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
 struct DecArgs { float* cbox; float* cconf; int* ccls; int A, aoff, stride, keep_logits; };
 constexpr int DEC_ROW = 68;                        // floats per pixel row of the box detour (64 + 4: conflict-free b128 rows)
 
-template <int MT, int KS, bool TAIL16 = false, int DEC = 0>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), via the K = 16 MFMA
+template <int MT, int KS, bool TAIL16 = false, int DEC = 0>      // TAIL16: 16 more input channels after the KS whole steps (cin = 80), as a zero-padded K = 32 step
 __global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvArgs a, int n_tiles, DecArgs dec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     constexpr int NT = 2, cin = KS * 32 + (TAIL16 ? 16 : 0), wrowb = ws_stride(cin * 2), parts = cin >> 3;
@@ -577,8 +576,9 @@ __global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvAr
     const int wstride = gridDim.x * NWV;
     for (int t = blockIdx.x * NWV + wave; t < n_tiles; t += wstride) {
         half8 B[KS][NT];
-        half4 Bt[NT];
+        half8 Bt[NT];
         long pix[NT];
+        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const long p = (long)t * 32 + nt * 16 + l15;
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvAr
             const half_t* src = px0 + 8 * h;
 #pragma unroll
             for (int k = 0; k < KS; ++k) B[k][nt] = *reinterpret_cast<const half8*>(src + k * 32);
-            if (TAIL16) Bt[nt] = *reinterpret_cast<const half4*>(px0 + KS * 32 + 4 * h);
+            if (TAIL16) Bt[nt] = *reinterpret_cast<const half8*>(px0 + KS * 32 + 8 * (h & 1));
         }
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -604,16 +604,14 @@ __global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvAr
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[k][nt], acc[mt][nt], 0, 0, 0);
         }
-        if (TAIL16) {            // (MT NT - 1 other MFMAs lie between this one and the K = 32 MFMA it accumulates onto: see c2f16_fused_kernel)
-            typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+        if (TAIL16) {            // the last 16 channels as a K = 32 step zero-padded in registers (lane groups 2, 3): conv_mfma_kernel's padded
+            // K to the bit, and no K = 16 MFMA behind a K = 32 one (see conv3x3_ws_kernel)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const h4v a4 = *reinterpret_cast<const h4v*>(lsm + (size_t)(mt * 16 + l15) * wrowb + KS * 64 + 8 * h);
+                const half8 av = *reinterpret_cast<const half8*>(lsm + (size_t)(mt * 16 + l15) * wrowb + KS * 64 + 16 * (h & 1));
+                const half8 a8 = h < 2 ? av : z8;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const h4v b4 = {Bt[nt].x, Bt[nt].y, Bt[nt].z, Bt[nt].w};
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[mt][nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, h < 2 ? Bt[nt] : z8, acc[mt][nt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1442,7 +1440,8 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
             AV_LAUNCH_CHECK();
             return AV_OK;
         }
-        if (a.ksz == 1 && a.stride == 1 && a.cin == 80 && a.cout == 80 && op.mt == 5 && !a.res && !force_direct) {
+        const bool generic80 = a.cin == 80 && getenv("AVHOT_CONV_GENERIC80");      // test hook: the cin = 80 layers on the generic kernels
+        if (a.ksz == 1 && a.stride == 1 && a.cin == 80 && a.cout == 80 && op.mt == 5 && !a.res && !force_direct && !generic80) {
             const size_t lds = (size_t)80 * ws_stride(160);
             const int n_tiles = (a.npix + 31) / 32;
             const dim3 g((unsigned)std::max(1, std::min((n_tiles + 3) / 4, 1024)));
@@ -1504,7 +1503,7 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
         const int cinp = a.cin == 80 ? 80 : (a.cin + 31) & ~31;       // channels per pixel in the LDS image
         const bool ws_shape = a.stride == 1 && a.ksz == 3 && a.cin % 8 == 0 && a.cout == 16 * op.mt &&
                               ((cinp == 32 && op.mt <= 2) || (cinp == 64 && (op.mt == 4 || op.mt == 5)) || (cinp == 80 && op.mt == 5));
-        if (ws_shape && !force_direct && !getenv("AVHOT_CONV_NO_WS")) {
+        if (ws_shape && !force_direct && !generic80 && !getenv("AVHOT_CONV_NO_WS")) {
             const long tiles16 = (long)((a.Wo + LT_W - 1) / LT_W) * ((a.Ho + 15) / 16) * B;
             int TR = tiles16 >= 512 ? 16 : 8;                   // tile rows
             auto lds_of = [&](int tr) {

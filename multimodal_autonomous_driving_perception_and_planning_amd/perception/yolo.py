@@ -2,6 +2,10 @@
 
 The reference calls ultralytics `YOLO("yolov8n.pt")(frame)` (detector.py:77-84,103-123); neither the
 package nor the weight file can be shipped, so this model takes its parameters from
+  * a YOLOv8n `state_dict` file with ultralytics' key names (`model.0.conv.weight`, `model.0.bn.running_mean`, ...,
+    `model.22.cv3.2.2.bias`): `.pt` / `.pth` / `.bin` read with `torch.load(weights_only=True)`, `.safetensors`, or an
+    `.npz` of such arrays -- `torch.save(YOLO("yolov8n.pt").model.state_dict(), "yolov8n_sd.pt")` on a machine with
+    ultralytics produces one (the pickled `DetectionModel` inside `yolov8n.pt` itself needs that package to load),
   * a `.npy` / `.npz` file holding the flat float32 vector in the order of `conv_specs()`, or
   * the pseudo path "random" / "random:<seed>" -> seeded He-normal weights with non-trivial BatchNorm
     statistics (BASELINE config 3: "random-init nano backbone").
@@ -63,17 +67,110 @@ def random_params(seed=0):
     return np.concatenate(parts)
 
 
+def ultralytics_layer_names():
+    """The module path of every convolution of conv_specs(), in that order, in ultralytics' YOLOv8n `state_dict`
+    (`model.<layer>.…`; a Conv block holds `.conv.weight` + `.bn.{weight,bias,running_mean,running_var}`, the two plain
+    Conv2d that end a Detect branch hold `.weight` + `.bias`) -- yolov8.yaml layer numbers, nn/modules/{conv,block,head}.py:
+    C2f = cv1, m.<i>.cv1, m.<i>.cv2, cv2; SPPF = cv1, cv2; Detect = cv2.<level>.<0..2> (box), cv3.<level>.<0..2> (class)."""
+    def c2f(layer, n):
+        return (["%d.cv1" % layer] + [q for i in range(n) for q in ("%d.m.%d.cv1" % (layer, i), "%d.m.%d.cv2" % (layer, i))]
+                + ["%d.cv2" % layer])
+    names = ["0", "1"] + c2f(2, 1) + ["3"] + c2f(4, 2) + ["5"] + c2f(6, 2) + ["7"] + c2f(8, 1) + ["9.cv1", "9.cv2"]
+    names += c2f(12, 1) + c2f(15, 1) + ["16"] + c2f(18, 1) + ["19"] + c2f(21, 1)
+    for lvl in range(3):
+        names += ["22.cv2.%d.%d" % (lvl, j) for j in range(3)] + ["22.cv3.%d.%d" % (lvl, j) for j in range(3)]
+    return names
+
+
+def params_from_state_dict(sd):
+    """Flat parameter vector (the order of conv_specs()) from a YOLOv8n `state_dict` with ultralytics' key names
+    (detector.py:77-84 loads such a model through `YOLO(model_path)`).  Keys may carry any number of leading `model.` /
+    `module.` prefixes; `num_batches_tracked` and the constant DFL convolution (`22.dfl.conv.weight`, arange(16)) are
+    ignored; every shape is checked.  BatchNorm is folded later by the library (eps 1e-3, ultralytics' Conv default)."""
+    import re
+    flat = {}
+    for k, v in sd.items():
+        k = re.sub(r"^(?:(?:model|module)\.)+", "", k)
+        flat[k] = v
+    specs, names = conv_specs(), ultralytics_layer_names()
+    assert len(specs) == len(names)
+
+    def get(key, shape):
+        if key not in flat:
+            raise KeyError("state_dict has no %r (a YOLOv8n checkpoint's state_dict is expected)" % ("model." + key))
+        a = flat[key]
+        a = a.detach().cpu().float().numpy() if hasattr(a, "detach") else np.asarray(a, np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, YOLOv8n (scale n) needs %s" % (key, tuple(a.shape), tuple(shape)))
+        return np.ascontiguousarray(a, np.float32).ravel()
+    parts = []
+    for (cin, cout, k, _, bn), name in zip(specs, names):
+        if bn:
+            parts.append(get(name + ".conv.weight", (cout, cin, k, k)))
+            parts += [get(name + ".bn." + q, (cout,)) for q in ("weight", "bias", "running_mean", "running_var")]
+        else:
+            parts += [get(name + ".weight", (cout, cin, k, k)), get(name + ".bias", (cout,))]
+    return np.concatenate(parts)
+
+
+def state_dict_from_params(params, prefix="model."):
+    """Inverse of params_from_state_dict (NumPy arrays under ultralytics' key names): lets a parameter vector of this
+    project be handed to code that expects a YOLOv8n state_dict, and is what the round-trip test uses."""
+    params = np.asarray(params, np.float32).ravel()
+    sd, pos = {}, 0
+    for (cin, cout, k, _, bn), name in zip(conv_specs(), ultralytics_layer_names()):
+        nw = cout * cin * k * k
+        w = params[pos:pos + nw].reshape(cout, cin, k, k)
+        pos += nw
+        if bn:
+            sd[prefix + name + ".conv.weight"] = w
+            for q in ("weight", "bias", "running_mean", "running_var"):
+                sd[prefix + name + ".bn." + q] = params[pos:pos + cout]
+                pos += cout
+        else:
+            sd[prefix + name + ".weight"] = w
+            sd[prefix + name + ".bias"] = params[pos:pos + cout]
+            pos += cout
+    assert pos == params.size
+    return sd
+
+
+def _load_checkpoint(model_path):
+    """A torch file (`.pt` / `.pth` / `.bin`) or `.safetensors` -> state_dict.  Only plain tensor containers are read
+    (`weights_only=True`): a state_dict, or a dict holding one under "state_dict" / "model_state_dict" / "model".  An
+    ultralytics training checkpoint pickles the whole `DetectionModel` object, which cannot be rebuilt without that package --
+    save `YOLO("yolov8n.pt").model.state_dict()` once instead."""
+    if model_path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        return load_file(model_path)
+    try:
+        obj = torch.load(model_path, map_location="cpu", weights_only=True)
+    except Exception as e:                                  # pickled module classes (ultralytics.nn.tasks.DetectionModel, ...)
+        raise FileNotFoundError("%r is not a plain state_dict file (%s: %s); export one with "
+                                "torch.save(YOLO(path).model.state_dict(), out)" % (model_path, type(e).__name__, str(e)[:120]))
+    for key in ("state_dict", "model_state_dict", "model"):
+        if isinstance(obj, dict) and isinstance(obj.get(key), dict):
+            obj = obj[key]
+    if not isinstance(obj, dict):
+        raise FileNotFoundError("%r holds a %s, not a state_dict" % (model_path, type(obj).__name__))
+    return obj
+
+
 def load_params(model_path):
     if model_path.startswith("random"):
         seed = int(model_path.split(":")[1]) if ":" in model_path else 0
         return random_params(seed)
     if not os.path.exists(model_path):
-        raise FileNotFoundError("model file %r not found (ultralytics checkpoints cannot be read here; "
-                                "pass a .npy/.npz parameter vector or 'random[:seed]')" % model_path)
+        raise FileNotFoundError("model file %r not found (pass a YOLOv8n state_dict file (.pt/.pth/.safetensors), a "
+                                ".npy/.npz parameter vector or 'random[:seed]')" % model_path)
     if model_path.endswith(".npz"):
         z = np.load(model_path)
+        if len(z.files) > 1:                                # a state_dict saved with np.savez
+            return params_from_state_dict({k: z[k] for k in z.files})
         return np.ascontiguousarray(z[z.files[0]], np.float32).ravel()
-    return np.ascontiguousarray(np.load(model_path), np.float32).ravel()
+    if model_path.endswith(".npy"):
+        return np.ascontiguousarray(np.load(model_path), np.float32).ravel()
+    return params_from_state_dict(_load_checkpoint(model_path))
 
 
 class YoloV8n:

@@ -41,6 +41,37 @@ def match_detections(got_box, got_cls, want_box, want_cls, px=1.0):
     return pairs, miss, [int(j) for j in np.nonzero(~used)[0]], worst
 
 
+def _has_partner(box, cls, other_box, other_cls, px):
+    """For every (box, cls): is there a same-class box in the other set with every coordinate within px?"""
+    box, other_box = np.asarray(box, np.float64).reshape(-1, 4), np.asarray(other_box, np.float64).reshape(-1, 4)
+    cls, other_cls = np.asarray(cls), np.asarray(other_cls)
+    if len(box) == 0:
+        return np.zeros(0, bool)
+    if len(other_box) == 0:
+        return np.zeros(len(box), bool)
+    d = np.abs(box[:, None, :] - other_box[None, :, :]).max(axis=2)
+    d[cls[:, None] != other_cls[None, :]] = np.inf
+    return d.min(axis=1) <= px
+
+
+def selection_sets(got_box, got_cls, runs, px=1.0):
+    """The set-valued parity statement for an ill-conditioned selection (greedy NMS): `runs` = [(boxes, classes)] are the
+    oracle's own detections on its logits, unperturbed (first) and perturbed by noise of the device's error size.
+    core  = boxes of run 0 that every run keeps (their fate does not depend on the rounding noise),
+    union = boxes that some run keeps.
+    -> (core boxes the device lacks, device boxes outside the union, |core|, |union| summed over the runs)."""
+    b0, k0 = runs[0]
+    in_all = np.ones(len(b0), bool)
+    for b, k in runs[1:]:
+        in_all &= _has_partner(b0, k0, b, k, px)
+    core_b, core_k = np.asarray(b0).reshape(-1, 4)[in_all], np.asarray(k0)[in_all]
+    ub = np.concatenate([np.asarray(b, np.float64).reshape(-1, 4) for b, _ in runs])
+    uk = np.concatenate([np.asarray(k) for _, k in runs])
+    core_missing = int((~_has_partner(core_b, core_k, got_box, got_cls, px)).sum())
+    outside = int((~_has_partner(got_box, got_cls, ub, uk, px)).sum())
+    return core_missing, outside, int(in_all.sum()), len(ub)
+
+
 def spread_params(seed=0):
     """The seeded random YOLOv8n-topology parameter vector with the Detect head's final class convolutions rescaled so
     that confidences spread over (0, 1) instead of sitting within 1e-3 of each other (which is what plain random
