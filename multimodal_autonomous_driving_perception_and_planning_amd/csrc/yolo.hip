@@ -159,14 +159,17 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 constexpr int LT_H = 8, LT_W = 16, LT_CK = 32, LT_PIXB = LT_CK * 2 + 32;   // row strides = 32 mod 64 bytes: ds_read_b128's four 16-lane groups
 // ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md LDS) then touch every bank once; with 16 bytes of padding 7 of 8 slots collided 2-way
 
-template <int MT, int KS>     // KS: kernel size (1 or 3), stride 1
+// S = 2 (the two stride-2 layers with cin = 128: backbone 128 -> 256 and the neck's 128 -> 128): 17 x 33 patch
+// per chunk, pixel stride = 16 mod 32 bytes so that lanes two pixels apart stay conflict-free (see conv3x3_ws_kernel).
+constexpr int lt_pixb(int s) { return s == 1 ? LT_PIXB : LT_CK * 2 + 16; }
+template <int MT, int KS, int S = 1>     // KS: kernel size (1 or 3); S: stride
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    constexpr int taps = KS * KS, pad = KS >> 1, s = 1;
-    constexpr int PH = LT_H - 1 + KS, PW = LT_W - 1 + KS;
+    constexpr int taps = KS * KS, pad = KS >> 1, s = S, PIXB = lt_pixb(S);
+    constexpr int PH = (LT_H - 1) * S + KS, PW = (LT_W - 1) * S + KS;
     constexpr int wrowb = taps * LT_CK * 2 + 32;
     unsigned char* patch = lsm;
-    unsigned char* wts = lsm + (((size_t)PH * PW * LT_PIXB + 15) & ~size_t(15));
+    unsigned char* wts = lsm + (((size_t)PH * PW * PIXB + 15) & ~size_t(15));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
             const int pix = i >> 2, part = i & 3;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = iy_org + py, ix = ix_org + px;
-            p_l[k] = pix * LT_PIXB + part * 16;
+            p_l[k] = pix * PIXB + part * 16;
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) p_g[k] = ((n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8;
         }
     }
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
                 A[mt] = *reinterpret_cast<const half8*>(wts + (size_t)(mt * 16 + l15) * wrowb + (tap * LT_CK + 8 * h) * 2);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                B[nt] = *reinterpret_cast<const half8*>(patch + (size_t)(((2 * wave + nt) * s + ky) * PW + l15 * s + kx) * LT_PIXB + 16 * h);
+                B[nt] = *reinterpret_cast<const half8*>(patch + (size_t)(((2 * wave + nt) * s + ky) * PW + l15 * s + kx) * PIXB + 16 * h);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -977,6 +980,157 @@ __global__ void preprocess2_kernel(const uint8_t* __restrict__ bgr, int B, int h
     }
 }
 
+// Fused front end for frames that are exactly twice the letterboxed size (1280x720): 2:1 letterbox + stem (3 -> 16, k3 s2) +
+// layer 1 (16 -> 32, k3 s2) in ONE launch.  As three launches the 4-channel network input (127 MB per 64 frames) and the stem's
+// 1/2-resolution map (126 MB) are each written and read back -- 746 MB of traffic for 240 MB of compulsory bytes (frames in,
+// 1/4-resolution map out), every one of the three HBM-bound.  A workgroup owns an 8 x 16 tile of layer 1's output: the 35 x 67
+// network-input pixels under it are averaged from the frame into LDS (preprocess2_kernel's float expressions), the stem runs
+// on them (17 x 33 outputs = 36 MFMA groups, stem_conv_kernel's two K steps), its SiLU'd half outputs stay in LDS, and layer 1
+// reads them with conv3x3_ws_kernel<2,1,8,32,false,2>'s K steps (nine taps, 16 channels zero-padded to K = 32 in registers)
+// and epilogue: the output is bit-identical to the three launches (tests/test_gpu_yolo.py).  Halo recompute: 1.10x for the stem.
+struct FrontArgs {
+    const uint8_t* bgr; int fh, fw;                  // frames [B][fh][fw][3]
+    int H, W, top, nh;                               // network input size, letterbox rows [top, top + nh) (left = 0, nw = W)
+    const half_t* w_stem; const float* bs_stem;      // [16][64], k = ky*16 + kx*4 + c
+    const half_t* w_l1; const float* bs_l1; int kpad1;      // [32][kpad1], k = tap*16 + ci
+    half_t* out; int out_cs, out_coff, Ho, Wo;       // layer 1's output [B][Ho][Wo][32]
+    int tiles_x, tiles_y, n_tiles;
+};
+constexpr int FR_XR = 35, FR_XC = 68, FR_SR = 17, FR_SC = 33, FR_SPX = 48, FR_W1S = 288;
+constexpr int FR_OFF_S = FR_XR * FR_XC * 8, FR_OFF_W = FR_OFF_S + ((FR_SR * FR_SC * FR_SPX + 15) & ~15), FR_LDS = FR_OFF_W + 32 * FR_W1S;
+constexpr int FR_NTH = 512, FR_TASKS = (FR_XR * (FR_XC / 2) + FR_NTH - 1) / FR_NTH;
+
+__global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    unsigned char* XL = lsm;                        // [35][68] pixels of 4 halves (R G B 0); column index = X column - (4 ox0 - 3)
+    unsigned char* SL = lsm + FR_OFF_S;             // [17 * 33] stem outputs, 16 halves in 48 bytes
+    unsigned char* W1 = lsm + FR_OFF_W;             // layer 1's weights [32][9 taps][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    for (int i = tid; i < FR_OFF_S / 16; i += FR_NTH) reinterpret_cast<uint4*>(XL)[i] = make_uint4(0, 0, 0, 0);   // the pad column stays zero
+    for (int i = tid; i < 32 * 18; i += FR_NTH) {
+        const int row = i / 18, piece = i - row * 18;
+        *reinterpret_cast<uint4*>(W1 + row * FR_W1S + piece * 16) = *reinterpret_cast<const uint4*>(a.w_l1 + (size_t)row * a.kpad1 + piece * 8);
+    }
+    const half8 A0 = *reinterpret_cast<const half8*>(a.w_stem + l15 * 64 + 8 * h);
+    const half8 A1 = *reinterpret_cast<const half8*>(a.w_stem + l15 * 64 + 32 + 8 * h);
+    const float4 bs0 = *reinterpret_cast<const float4*>(a.bs_stem + 4 * h);
+    const float4 bs1a = *reinterpret_cast<const float4*>(a.bs_l1 + 4 * h), bs1b = *reinterpret_cast<const float4*>(a.bs_l1 + 16 + 4 * h);
+    asm volatile("" ::"v"(bs0.x), "v"(bs0.y), "v"(bs0.z), "v"(bs0.w), "v"(bs1a.x), "v"(bs1a.y), "v"(bs1a.z), "v"(bs1a.w), "v"(bs1b.x),
+                 "v"(bs1b.y), "v"(bs1b.z), "v"(bs1b.w));
+    const half_t pad114 = f2h(114.f / 255.f);
+    auto origin = [&](int t, int& n, int& oy0, int& ox0) {
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 8, ox0 = tx * 16;
+    };
+    // fill task k of this thread: row ty = i / 34 of the patch, pixel pair pp = i % 34 -> X columns x, x + 1 with x = 4 ox0 - 4 + 2 pp
+    // (even: the pair is 12 contiguous frame bytes of two rows, as in preprocess2_kernel)
+    unsigned fr0[FR_TASKS][3], fr1[FR_TASKS][3];
+    auto gload = [&](int t) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+        const uint8_t* im = a.bgr + (size_t)n * a.fh * a.fw * 3;
+#pragma unroll
+        for (int k = 0; k < FR_TASKS; ++k) {
+            const int i = tid + k * FR_NTH, ty = i / 34, pp = i - ty * 34;
+            const int y = 4 * oy0 - 3 + ty, x = 4 * ox0 - 4 + 2 * pp, yy = y - a.top;
+            const bool ok = i < FR_XR * 34 && yy >= 0 && yy < a.nh && x >= 0 && x < a.W;
+            const int yc = ok ? yy : 0, xc = ok ? x : 0;
+            const unsigned* r0 = reinterpret_cast<const unsigned*>(im + ((size_t)(2 * yc) * a.fw + 2 * xc) * 3);
+            const unsigned* r1 = reinterpret_cast<const unsigned*>(im + ((size_t)(2 * yc + 1) * a.fw + 2 * xc) * 3);
+            fr0[k][0] = r0[0], fr0[k][1] = r0[1], fr0[k][2] = r0[2], fr1[k][0] = r1[0], fr1[k][1] = r1[1], fr1[k][2] = r1[2];
+        }
+    };
+    int t = blockIdx.x;
+    if (t < a.n_tiles) gload(t);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+        __syncthreads();                                            // the previous tile is done with XL / SL (first trip: weights, zeros)
+        // ---- network-input patch: preprocess2_kernel's arithmetic ---------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < FR_TASKS; ++k) {
+            const int i = tid + k * FR_NTH, ty = i / 34, pp = i - ty * 34;
+            if (i >= FR_XR * 34) continue;
+            const int y = 4 * oy0 - 3 + ty, x = 4 * ox0 - 4 + 2 * pp, yy = y - a.top;
+            half_t v[2][4] = {{(half_t)0, (half_t)0, (half_t)0, (half_t)0}, {(half_t)0, (half_t)0, (half_t)0, (half_t)0}};
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {           // (x even and W even: both pixels of the pair are inside or outside)
+                if (yy >= 0 && yy < a.nh) {
+                    const unsigned a0 = fr0[k][0], b0 = fr0[k][1], c0 = fr0[k][2], a1 = fr1[k][0], b1 = fr1[k][1], c1 = fr1[k][2];
+                    auto px = [](unsigned aa, unsigned bb, unsigned cc, int p, int q) -> float {
+                        const int byte = p * 3 + q;
+                        const unsigned word = byte < 4 ? aa : (byte < 8 ? bb : cc);
+                        return (float)((word >> (8 * (byte & 3))) & 255u);
+                    };
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        float c[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            const float p00 = px(a0, b0, c0, 2 * o, q), p01 = px(a0, b0, c0, 2 * o + 1, q);
+                            const float p10 = px(a1, b1, c1, 2 * o, q), p11 = px(a1, b1, c1, 2 * o + 1, q);
+                            const float ta = p00 * (1.f - 0.5f) + p01 * 0.5f, tb = p10 * (1.f - 0.5f) + p11 * 0.5f;
+                            c[q] = floorf(ta * (1.f - 0.5f) + tb * 0.5f + 0.5f);
+                        }
+                        v[o][0] = f2h(c[2] / 255.f), v[o][1] = f2h(c[1] / 255.f), v[o][2] = f2h(c[0] / 255.f);      // RGB
+                    }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) v[o][0] = v[o][1] = v[o][2] = pad114;
+                }
+            }
+            const int lc = 2 * pp - 1;                              // local column of the pair's first pixel (-1: not part of the patch)
+            unsigned char* dst = XL + (ty * FR_XC + lc) * 8;
+            if (lc >= 0) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v[0]);
+            *reinterpret_cast<uint2*>(dst + 8) = *reinterpret_cast<const uint2*>(v[1]);
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);   // next tile's frame bytes in flight during this tile's MFMAs
+        // ---- stem: 17 x 33 outputs in 36 groups of 16 ---------------------------------------------------------------------------
+        for (int g = wave; g < 36; g += FR_NTH / 64) {
+            const int q = g * 16 + l15, qq = q < FR_SR * FR_SC ? q : FR_SR * FR_SC - 1;
+            const int sr = qq / FR_SC, sc = qq - sr * FR_SC;
+            const int sy = 2 * oy0 - 1 + sr, sx = 2 * ox0 - 1 + sc;
+            const bool inside = (unsigned)sy < (unsigned)(a.H / 2) && (unsigned)sx < (unsigned)(a.W / 2);
+            const unsigned char* xb = XL + ((2 * sr) * FR_XC + 2 * sc + 2 * (h & 1)) * 8;
+            const half8 B0 = *reinterpret_cast<const half8*>(xb + (h >> 1) * FR_XC * 8);
+            const half8 B1 = *reinterpret_cast<const half8*>(xb + 2 * FR_XC * 8);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, B0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, B1, acc, 0, 0, 0);
+            half4 o = make_half4(silu(acc[0] + bs0.x), silu(acc[1] + bs0.y), silu(acc[2] + bs0.z), silu(acc[3] + bs0.w));
+            if (!inside) o = half4{(half_t)0, (half_t)0, (half_t)0, (half_t)0};          // layer 1's zero padding
+            if (q < FR_SR * FR_SC) *reinterpret_cast<half4*>(SL + q * FR_SPX + 8 * h) = o;
+        }
+        __syncthreads();
+        // ---- layer 1: wave = output row, lane column; nine K = 32 steps with channels 16..31 zero ------------------------------------
+        {
+            const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            half8 bv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const half8 v = *reinterpret_cast<const half8*>(SL + ((2 * wave + tap / 3) * FR_SC + 2 * l15 + tap % 3) * FR_SPX + 16 * (h & 1));
+                bv[tap] = h < 2 ? v : z8;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const half8 w = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * FR_W1S + tap * 32 + 16 * (h & 1));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h < 2 ? w : z8, bv[tap], acc[mt], 0, 0, 0);
+                }
+            }
+            const int oy = oy0 + wave, ox = ox0 + l15;
+            if (oy < a.Ho && ox < a.Wo) {
+                half_t* op = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.out_cs + a.out_coff + 4 * h;
+                *reinterpret_cast<half4*>(op) = make_half4(silu(acc[0][0] + bs1a.x), silu(acc[0][1] + bs1a.y), silu(acc[0][2] + bs1a.z), silu(acc[0][3] + bs1a.w));
+                *reinterpret_cast<half4*>(op + 16) = make_half4(silu(acc[1][0] + bs1b.x), silu(acc[1][1] + bs1b.y), silu(acc[1][2] + bs1b.z), silu(acc[1][3] + bs1b.w));
+            }
+        }
+    }
+}
+
 __global__ void maxpool5_kernel(const half_t* in, int cs_in, int coff_in, half_t* out, int cs_out, int coff_out, int B,
                                 int H, int W, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1541,6 +1695,15 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
                 return AV_OK;
             }
         }
+        // stride-2 3x3 layers with cin a multiple of 32 that did not fit the weight-stationary kernel (cin = 128): chunked LDS kernel
+        if (a.stride == 2 && a.ksz == 3 && a.cin % LT_CK == 0 && op.mt == 4 && a.cout % 64 == 0 && !a.res && !force_direct &&
+            !getenv("AVHOT_CONV_NO_S2LDS")) {
+            const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
+            const size_t lds = (((size_t)17 * 33 * lt_pixb(2) + 15) & ~size_t(15)) + (size_t)64 * (9 * LT_CK * 2 + 32);
+            hipLaunchKernelGGL((conv_lds_kernel<4, 3, 2>), dim3(tiles_x * tiles_y * B, a.cout / 64), dim3(256), lds, st, a, tiles_x, tiles_y);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
         if (lds_ok && !force_direct) {
             const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
             const int taps = a.ksz * a.ksz;
@@ -1710,7 +1873,9 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(front_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS));
 #define AV_C1_ATTR(KSV) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<2, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<4, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
@@ -1778,11 +1943,26 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     const hipStream_t st_main = st;
     const int B = y.B;
     const bool force_direct = getenv("AVHOT_CONV_DIRECT") != nullptr;      // tuning aid, read once per forward
+    size_t first_op = 0;
     {
         const int n = B * y.H * y.W;
         const bool twice = y.inH == 2 * y.nh && y.inW == 2 * y.nw && y.inW % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0 &&
                            y.left % 2 == 0 && y.nw % 2 == 0 && y.W % 2 == 0 && !getenv("AVHOT_YOLO_GENERIC_PRE");
-        if (twice)
+        // letterbox + stem + layer 1 in one launch (front_fused_kernel); with keep_logits (test hook) the three launches run, so that
+        // the network input and the stem's map exist for inspection
+        const bool front = twice && y.left == 0 && y.nw == y.W && y.H % 4 == 0 && y.W % 4 == 0 && y.ops.size() > 2 && y.ops[0].kind == 4 &&
+                           y.ops[1].kind == 0 && y.ops[1].ca.cin == 16 && y.ops[1].ca.cout == 32 && y.ops[1].ca.stride == 2 && !y.keep_logits &&
+                           !force_direct && !getenv("AVHOT_YOLO_NO_FUSE") && !getenv("AVHOT_CONV_NO_WS");
+        if (front) {
+            const ConvArgs &c0 = y.ops[0].ca, &c1 = y.ops[1].ca;
+            FrontArgs fa;
+            fa.bgr = bgr, fa.fh = y.inH, fa.fw = y.inW, fa.H = y.H, fa.W = y.W, fa.top = y.top, fa.nh = y.nh;
+            fa.w_stem = c0.wgt, fa.bs_stem = c0.bias, fa.w_l1 = c1.wgt, fa.bs_l1 = c1.bias, fa.kpad1 = c1.kpad;
+            fa.out = c1.out, fa.out_cs = c1.out_cs, fa.out_coff = c1.out_coff, fa.Ho = c1.Ho, fa.Wo = c1.Wo;
+            fa.tiles_x = (c1.Wo + 15) / 16, fa.tiles_y = (c1.Ho + 7) / 8, fa.n_tiles = fa.tiles_x * fa.tiles_y * B;
+            hipLaunchKernelGGL(front_fused_kernel, dim3((unsigned)std::min(fa.n_tiles, 512)), dim3(FR_NTH), FR_LDS, st, fa);
+            first_op = 2;
+        } else if (twice)
             hipLaunchKernelGGL(preprocess2_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh,
                                y.nw, y.top, y.left, y.bufs[0].p);
         else
@@ -1793,7 +1973,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     // (Walking the chain with 2 or 4 sub-batches of the frames on as many streams was measured, to let one group's per-launch
     // latency hide behind another's work: 1.78 -> 1.80 / 1.99 ms at 64 frames -- every launch already occupies the whole chip,
     // so the groups only queue behind each other; dropped)
-    for (size_t oi = 0; oi < y.ops.size(); ++oi) {
+    for (size_t oi = first_op; oi < y.ops.size(); ++oi) {
         const Yolo::Op& op = y.ops[oi];
         if ((int)oi == y.head_begin && y.tail_pending)     // the previous forward's sort + NMS must be done with the candidates the head rewrites
             AV_HIP(hipStreamWaitEvent(st_main, y.ev_tail, 0));

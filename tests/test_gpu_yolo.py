@@ -160,9 +160,9 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
             eb, ec = max(eb, float(db)), max(ec, float(dc))
         return eb, ec
 
-    def set_statement(tag, k, f, eb, ec, gb, gk, rs):
+    def set_statement(tag, k, f, eb, ec, gb, gk, rs, trials=TRIALS, outside_allowed=0):
         runs = [post(f["head"])]
-        for trial in range(TRIALS):
+        for trial in range(trials):
             hd = [(b + torch.from_numpy(rs.uniform(-eb, eb, tuple(b.shape)).astype(np.float32)),
                    c + torch.from_numpy(rs.uniform(-ec, ec, tuple(c.shape)).astype(np.float32))) for b, c in f["head"]]
             runs.append(post(hd))
@@ -174,7 +174,7 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
               "core boxes missing %d, device boxes outside the union of %d runs: %d; logit error box %.2g cls %.2g"
               % (tag, k, len(wb), len(gb), len(pairs), (len(miss) + len(extra)) / max(1, len(gb) + len(wb)), n_core,
                  core_missing, len(runs), outside, eb, ec))
-        assert core_missing == 0 and outside == 0, (tag, k, core_missing, outside)
+        assert core_missing == 0 and outside <= outside_allowed, (tag, k, core_missing, outside)
         assert worst <= 1.0
         return n_core
 
@@ -233,32 +233,45 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
             f = net0.features(torch.from_numpy(R.preprocess(fr))[None])
         model.detect(fr)
         eb, ec = logit_error(model, f)
-        set_statement("random:0", k, f, eb, ec, gb, gk, rs)
+        # 300 kept boxes out of ~1700 walked, many of them kept in only a few per cent of the outcomes: a finite number of runs
+        # cannot cover every box of one particular outcome, so 1 % of the device's boxes may lie outside the union of 96 runs
+        # (measured: 3 of 300 outside 24 runs); the stable core must be kept without exception
+        set_statement("random:0", k, f, eb, ec, gb, gk, rs, trials=96, outside_allowed=len(gb) // 100)
     prod0.close()
 
 
-def test_fused_c2f_block_is_bit_identical_to_its_four_launches(setup, monkeypatch):
-    """c2f16_fused_kernel (layer 2: cv1, 3x3, 3x3 + shortcut, cv2 in one launch) against the four-launch path
-    (AVHOT_YOLO_NO_FUSE, read per forward): every element of the block's output, borders included, on frames with
-    different content, in a batch large enough that persistent workgroups walk more than one tile."""
+def test_fused_kernels_are_bit_identical_to_their_separate_launches(setup, monkeypatch):
+    """front_fused_kernel (2:1 letterbox + stem + layer 1 in one launch) and c2f16_fused_kernel (layer 2: cv1, 3x3,
+    3x3 + shortcut, cv2 in one launch) against the separate launches (AVHOT_YOLO_NO_FUSE, read per forward): every
+    element of layer 1's and layer 2's outputs, borders included, on frames with different content, in a batch large
+    enough that persistent workgroups walk more than one tile -- and the detections that come out at the end."""
     import torch
     Y, R, frame, feats, model, _ = setup
     from oracle.lane_ref import synthetic_frame
+    rs = np.random.RandomState(11)
     frames = [frame] + [synthetic_frame(720, 1280, s, f) for s, f in ((6, 40), (2, 77))] + [np.full((720, 1280, 3), 255, np.uint8)]
-    frames = frames * 3                                  # 12 images = 720 tiles on 512 persistent workgroups: some walk two tiles
+    frames.append(rs.randint(0, 256, (720, 1280, 3)).astype(np.uint8))          # noise: every pixel of every halo matters
+    frames = frames * 3                                  # 15 images: 1800 front tiles / 900 layer-2 tiles on 512 persistent workgroups
     m = Y.YoloV8n("random:0", batch=len(frames))
     m._prepare(720, 1280)
     m._frames.copy_(torch.as_tensor(np.stack(frames)))
 
-    def layer2_all():
+    def run():
         m.forward_device(m._frames)
-        return m.tensor(2, image=None)
-    fused = layer2_all()
+        torch.cuda.synchronize()
+        return (m.tensor(1, image=None), m.tensor(2, image=None), m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(),
+                m._conf.cpu().numpy().copy())
+    fused = run()
     monkeypatch.setenv("AVHOT_YOLO_NO_FUSE", "1")
-    unfused = layer2_all()
+    unfused = run()
     monkeypatch.delenv("AVHOT_YOLO_NO_FUSE")
-    assert fused.shape == (len(frames), 96, 160, 32) and fused.any()
-    assert np.array_equal(fused.view(np.uint32), unfused.view(np.uint32)), int((fused != unfused).sum())
+    assert fused[0].shape == (len(frames), 96, 160, 32) and fused[0].any() and fused[1].shape == (len(frames), 96, 160, 32) and fused[1].any()
+    for k, name in ((0, "layer 1"), (1, "layer 2")):
+        assert np.array_equal(fused[k].view(np.uint32), unfused[k].view(np.uint32)), (name, int((fused[k] != unfused[k]).sum()))
+    assert np.array_equal(fused[2], unfused[2]) and np.array_equal(fused[3], unfused[3]) and np.array_equal(fused[4], unfused[4])
+    # the keep_logits model (three launches, network input and stem map kept) gives the same layer-1 map as the production path
+    model.detect(frames[4])
+    assert np.array_equal(model.tensor(1).view(np.uint32), fused[0][4].view(np.uint32))
     m.close()
 
 
