@@ -159,14 +159,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
 constexpr int LT_H = 8, LT_W = 16, LT_CK = 32, LT_PIXB = LT_CK * 2 + 32;   // row strides = 32 mod 64 bytes: ds_read_b128's four 16-lane groups
 // ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md LDS) then touch every bank once; with 16 bytes of padding 7 of 8 slots collided 2-way
 
-// S = 2 (the two stride-2 layers with cin = 128: backbone 128 -> 256 and the neck's 128 -> 128): 17 x 33 patch
-// per chunk, pixel stride = 16 mod 32 bytes so that lanes two pixels apart stay conflict-free (see conv3x3_ws_kernel).
-constexpr int lt_pixb(int s) { return s == 1 ? LT_PIXB : LT_CK * 2 + 16; }
-template <int MT, int KS, int S = 1>     // KS: kernel size (1 or 3); S: stride
+template <int MT, int KS>     // KS: kernel size (1 or 3), stride 1.  (A stride-2 instance for the two cin = 128 stride-2 layers -- 17 x 33
+// patch per chunk -- was measured in round 3: 62.6 / 34.3 us against conv_mfma_kernel's 53.8 / 29.3 us; not kept.)
 __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    constexpr int taps = KS * KS, pad = KS >> 1, s = S, PIXB = lt_pixb(S);
-    constexpr int PH = (LT_H - 1) * S + KS, PW = (LT_W - 1) * S + KS;
+    constexpr int taps = KS * KS, pad = KS >> 1, s = 1, PIXB = LT_PIXB;
+    constexpr int PH = LT_H - 1 + KS, PW = LT_W - 1 + KS;
     constexpr int wrowb = taps * LT_CK * 2 + 32;
     unsigned char* patch = lsm;
     unsigned char* wts = lsm + (((size_t)PH * PW * PIXB + 15) & ~size_t(15));
@@ -997,7 +995,8 @@ struct FrontArgs {
     int tiles_x, tiles_y, n_tiles;
 };
 constexpr int FR_XR = 35, FR_XC = 68, FR_SR = 17, FR_SC = 33, FR_SPX = 48, FR_W1S = 288;
-constexpr int FR_OFF_S = FR_XR * FR_XC * 8, FR_OFF_W = FR_OFF_S + ((FR_SR * FR_SC * FR_SPX + 15) & ~15), FR_LDS = FR_OFF_W + 32 * FR_W1S;
+constexpr int FR_OFF_S = FR_XR * FR_XC * 8, FR_OFF_W = FR_OFF_S + ((FR_SR * FR_SC * FR_SPX + 15) & ~15), FR_OFF_LUT = FR_OFF_W + 32 * FR_W1S,
+              FR_LDS = FR_OFF_LUT + 512;
 constexpr int FR_NTH = 512, FR_TASKS = (FR_XR * (FR_XC / 2) + FR_NTH - 1) / FR_NTH;
 
 __global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
@@ -1005,12 +1004,14 @@ __global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
     unsigned char* XL = lsm;                        // [35][68] pixels of 4 halves (R G B 0); column index = X column - (4 ox0 - 3)
     unsigned char* SL = lsm + FR_OFF_S;             // [17 * 33] stem outputs, 16 halves in 48 bytes
     unsigned char* W1 = lsm + FR_OFF_W;             // layer 1's weights [32][9 taps][16]
+    half_t* LUT = reinterpret_cast<half_t*>(lsm + FR_OFF_LUT);     // byte level -> half(level / 255): preprocess2_kernel's last step, tabulated
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     for (int i = tid; i < FR_OFF_S / 16; i += FR_NTH) reinterpret_cast<uint4*>(XL)[i] = make_uint4(0, 0, 0, 0);   // the pad column stays zero
     for (int i = tid; i < 32 * 18; i += FR_NTH) {
         const int row = i / 18, piece = i - row * 18;
         *reinterpret_cast<uint4*>(W1 + row * FR_W1S + piece * 16) = *reinterpret_cast<const uint4*>(a.w_l1 + (size_t)row * a.kpad1 + piece * 8);
     }
+    if (tid < 256) LUT[tid] = f2h((float)tid / 255.f);
     const half8 A0 = *reinterpret_cast<const half8*>(a.w_stem + l15 * 64 + 8 * h);
     const half8 A1 = *reinterpret_cast<const half8*>(a.w_stem + l15 * 64 + 32 + 8 * h);
     const float4 bs0 = *reinterpret_cast<const float4*>(a.bs_stem + 4 * h);
@@ -1046,42 +1047,36 @@ __global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();                                            // the previous tile is done with XL / SL (first trip: weights, zeros)
-        // ---- network-input patch: preprocess2_kernel's arithmetic ---------------------------------------------------------
+        // ---- network-input patch.  preprocess2_kernel computes floor((p00/2 + p01/2)/2 + (p10/2 + p11/2)/2 + 0.5) in floats, every
+        // step exact, i.e. (p00 + p01 + p10 + p11 + 2) >> 2, then half(level / 255): here the four-byte sums are made on packed 16-bit
+        // pairs (rows added first) and the division + rounding come from a 256-entry table built with that very expression ------
 #pragma unroll
         for (int k = 0; k < FR_TASKS; ++k) {
             const int i = tid + k * FR_NTH, ty = i / 34, pp = i - ty * 34;
             if (i >= FR_XR * 34) continue;
             const int y = 4 * oy0 - 3 + ty, x = 4 * ox0 - 4 + 2 * pp, yy = y - a.top;
-            half_t v[2][4] = {{(half_t)0, (half_t)0, (half_t)0, (half_t)0}, {(half_t)0, (half_t)0, (half_t)0, (half_t)0}};
+            uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
             if (y >= 0 && y < a.H && x >= 0 && x < a.W) {           // (x even and W even: both pixels of the pair are inside or outside)
                 if (yy >= 0 && yy < a.nh) {
-                    const unsigned a0 = fr0[k][0], b0 = fr0[k][1], c0 = fr0[k][2], a1 = fr1[k][0], b1 = fr1[k][1], c1 = fr1[k][2];
-                    auto px = [](unsigned aa, unsigned bb, unsigned cc, int p, int q) -> float {
-                        const int byte = p * 3 + q;
-                        const unsigned word = byte < 4 ? aa : (byte < 8 ? bb : cc);
-                        return (float)((word >> (8 * (byte & 3))) & 255u);
-                    };
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        float c[3];
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            const float p00 = px(a0, b0, c0, 2 * o, q), p01 = px(a0, b0, c0, 2 * o + 1, q);
-                            const float p10 = px(a1, b1, c1, 2 * o, q), p11 = px(a1, b1, c1, 2 * o + 1, q);
-                            const float ta = p00 * (1.f - 0.5f) + p01 * 0.5f, tb = p10 * (1.f - 0.5f) + p11 * 0.5f;
-                            c[q] = floorf(ta * (1.f - 0.5f) + tb * 0.5f + 0.5f);
-                        }
-                        v[o][0] = f2h(c[2] / 255.f), v[o][1] = f2h(c[1] / 255.f), v[o][2] = f2h(c[0] / 255.f);      // RGB
-                    }
+                    // bytes of a row: a = B0 G0 R0 B1 | b = G1 R1 B2 G2 | c = R2 B3 G3 R3; E = (byte 0, byte 2), O = (byte 1, byte 3) of both rows added
+                    constexpr unsigned M = 0x00FF00FFu;
+                    const unsigned Ea = (fr0[k][0] & M) + (fr1[k][0] & M), Oa = ((fr0[k][0] >> 8) & M) + ((fr1[k][0] >> 8) & M);
+                    const unsigned Eb = (fr0[k][1] & M) + (fr1[k][1] & M), Ob = ((fr0[k][1] >> 8) & M) + ((fr1[k][1] >> 8) & M);
+                    const unsigned Ec = (fr0[k][2] & M) + (fr1[k][2] & M), Oc = ((fr0[k][2] >> 8) & M) + ((fr1[k][2] >> 8) & M);
+                    const unsigned b0 = ((Ea & 0xFFFFu) + (Oa >> 16) + 2u) >> 2, g0 = ((Oa & 0xFFFFu) + (Eb & 0xFFFFu) + 2u) >> 2, r0 = ((Ea >> 16) + (Ob & 0xFFFFu) + 2u) >> 2;
+                    const unsigned b1 = ((Eb >> 16) + (Oc & 0xFFFFu) + 2u) >> 2, g1 = ((Ob >> 16) + (Ec >> 16) + 2u) >> 2, r1 = ((Ec & 0xFFFFu) + (Oc >> 16) + 2u) >> 2;
+                    const unsigned short* lut = reinterpret_cast<const unsigned short*>(LUT);
+                    v0 = make_uint2((unsigned)lut[r0] | ((unsigned)lut[g0] << 16), (unsigned)lut[b0]);              // R G B 0
+                    v1 = make_uint2((unsigned)lut[r1] | ((unsigned)lut[g1] << 16), (unsigned)lut[b1]);
                 } else {
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) v[o][0] = v[o][1] = v[o][2] = pad114;
+                    const unsigned p = __builtin_bit_cast(unsigned short, pad114);
+                    v0 = v1 = make_uint2(p | (p << 16), p);
                 }
             }
             const int lc = 2 * pp - 1;                              // local column of the pair's first pixel (-1: not part of the patch)
             unsigned char* dst = XL + (ty * FR_XC + lc) * 8;
-            if (lc >= 0) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v[0]);
-            *reinterpret_cast<uint2*>(dst + 8) = *reinterpret_cast<const uint2*>(v[1]);
+            if (lc >= 0) *reinterpret_cast<uint2*>(dst) = v0;
+            *reinterpret_cast<uint2*>(dst + 8) = v1;
         }
         __syncthreads();
         if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);   // next tile's frame bytes in flight during this tile's MFMAs
@@ -1239,78 +1234,140 @@ __global__ void decode_kernel(Level l0, Level l1, Level l2, int A, int B, float*
     ccls[i] = bj;
 }
 
-// per image: candidates with conf > thres sorted by (conf desc, anchor asc) -> class-offset boxes
-__global__ void __launch_bounds__(1024) nms_sort_kernel(int A, float conf_thres, const float* __restrict__ cbox,
+// per image: candidates with conf > thres sorted by (conf desc, anchor asc) -> class-offset boxes.
+// Stable LSD radix sort in LDS.  A confidence in (thres, 1] has float bits below 0x3F800000 and above 0x3E000000 (thres >= 2^-3 ...
+// any positive threshold works: the key is v = 0x3F800000 - bits, ascending v = descending confidence, and the passes cover as
+// many 8-bit digits as the largest v needs: three for thresholds >= 2^-1 ... 0.25 gives v < 2^24).  The candidates enter in anchor
+// order and every pass is stable, so equal confidences leave in anchor order -- the oracle's tie rule -- without the anchor in the key.
+// One pass: elements are dealt round-robin (element i = round 1024 + thread), so inside a round array order = thread order; a
+// wave ranks its 64 elements per digit with eight ballots (match-any), the first lane of every digit group stores the group's size
+// in cnt[digit][round][wave], an exclusive scan over that table (digit-major) turns sizes into destinations, and the element goes
+// to  scan[digit][round][wave] + rank inside its group.  Round 2's bitonic network over 8192 padded 64-bit keys took 67 us (60 us
+// with the keys in registers and lane exchanges: 45 of its 91 stages are wave-wide exchanges of eight 64-bit keys).
+// DB: digit bits.  LDS = two (key, anchor) images of `cap` = 1024 rounds entries + the table: 8-bit digits fit up to 7 rounds (7168
+// anchors), the full 8192 take 7-bit digits (one pass more).
+constexpr int RS_ROUNDS = MAX_CAND / 1024;
+constexpr size_t rs_lds(int rounds, int db) { return (size_t)2 * rounds * 1024 * 6 + (size_t)(1 << db) * rounds * 16 * 2; }
+template <int DB>
+__global__ void __launch_bounds__(1024) nms_sort_kernel(int A, int rounds, float conf_thres, const float* __restrict__ cbox,
                                                         const float* __restrict__ cconf, const int* __restrict__ ccls,
                                                         float* __restrict__ sbox, int* __restrict__ sidx, int* __restrict__ scount) {
-    __shared__ unsigned long long key[MAX_CAND];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < MAX_CAND; i += 1024) {
-        unsigned long long k = ~0ull;                         // sorts last
-        if (i < A) {
-            const float c = cconf[(size_t)n * A + i];
-            if (c > conf_thres) k = ((unsigned long long)(~__float_as_uint(c)) << 32) | (unsigned)i;   // conf > 0: bits monotone
-        }
-        key[i] = k;
-    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
+    const int cap = rounds * 1024, ncnt = (1 << DB) * rounds * 16;
+    unsigned* kv = reinterpret_cast<unsigned*>(sort_smem);                    // [2][cap] keys v (ping-pong)
+    unsigned short* ki = reinterpret_cast<unsigned short*>(kv + 2 * cap);     // [2][cap] anchors
+    unsigned short* cnt = ki + 2 * cap;                                       // [1 << DB][rounds][16]
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned s_n, s_vmax;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (tid == 0) s_n = 0, s_vmax = 0;
     __syncthreads();
-    // bitonic network; strides >= 8 go through LDS one stage per barrier, the last three stages of every merge
-    // (strides 4, 2, 1) stay inside a thread's 8 consecutive keys and run in registers
-    static_assert(MAX_CAND % 8192 == 0, "a thread owns 8 consecutive keys per 8192");
-    auto cmpx = [](unsigned long long& a, unsigned long long& b, bool up) {
-        if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
-    };
-    for (int sz = 2; sz <= MAX_CAND; sz <<= 1) {
-        for (int ls = 31 - __clz(sz >> 1); ls >= 3; --ls) {
-            const int st = 1 << ls;
-            for (int i = tid; i < MAX_CAND / 2; i += 1024) {
-                const int lo = ((i >> ls) << (ls + 1)) | (i & (st - 1)), hi = lo + st;
-                const bool up = ((lo & sz) == 0);
-                const unsigned long long a = key[lo], b = key[hi];
-                if ((a > b) == up) key[lo] = b, key[hi] = a;
+    // ---- compaction in anchor order: valid candidates -> kv[0], ki[0] -------------------------------------------------------------
+    {
+        unsigned run = 0, vmax = 0;                                           // candidates are taken in blocks of 1024: block order = anchor order
+        float cc[RS_ROUNDS];                                                  // all confidences of this thread first: one exposed load latency, not one per block
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) cc[r] = (r < rounds && r * 1024 + tid < A) ? cconf[(size_t)n * A + r * 1024 + tid] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            if (r >= rounds) break;
+            const int i = r * 1024 + tid;
+            const float c = cc[r];
+            const bool ok = i < A && c > conf_thres && c <= 1.0f;
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) wsum[wid] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const unsigned v = wsum[w];
+                before += w < wid ? v : 0u, total += v;
             }
+            if (ok) {
+                const unsigned pos = run + before + (unsigned)__popcll(m & lt), v = 0x3F800000u - __float_as_uint(c);
+                kv[pos] = v, ki[pos] = (unsigned short)i;
+                vmax = vmax > v ? vmax : v;
+            }
+            run += total;
             __syncthreads();
         }
-        for (int base = tid * 8; base < MAX_CAND; base += 8192) {
-            unsigned long long k[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) k[q] = key[base + q];
-            const bool up = ((base & sz) == 0);                  // sz >= 8: one direction for the whole octet
-            if (sz >= 8) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cmpx(k[q], k[q + 4], up);
-            }
-            if (sz >= 4) {
-#pragma unroll
-                for (int q = 0; q < 8; q += 4) {
-                    const bool u = sz >= 8 ? up : (((base + q) & sz) == 0);
-                    cmpx(k[q], k[q + 2], u), cmpx(k[q + 1], k[q + 3], u);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) {
-                const bool u = sz >= 8 ? up : (((base + q) & sz) == 0);
-                cmpx(k[q], k[q + 1], u);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) key[base + q] = k[q];
-        }
+        if (vmax) atomicMax(&s_vmax, vmax);
+        if (tid == 0) s_n = run;
         __syncthreads();
     }
-    for (int i = tid; i < A; i += 1024) {
-        const unsigned long long k = key[i];
-        if (k != ~0ull) {
-            const int a = (int)(unsigned)k;
-            const float off = (float)ccls[(size_t)n * A + a] * 7680.0f;
-            const float* b = cbox + ((size_t)n * A + a) * 4;
-            float* o = sbox + ((size_t)n * A + i) * 4;
-            o[0] = b[0] + off, o[1] = b[1] + off, o[2] = b[2] + off, o[3] = b[3] + off;
-            sidx[(size_t)n * A + i] = a;
-            if (i == A - 1 || key[i + 1] == ~0ull) scount[n] = i + 1;       // valid keys sort first
-        } else if (i == 0) {
-            scount[n] = 0;
+    const int cntv = (int)s_n;
+    const unsigned vmax = s_vmax;
+    int src = 0;
+    for (int shift = 0; shift < 32 && (vmax >> shift) != 0; shift += DB) {
+        for (int i = tid; i < ncnt / 2; i += 1024) reinterpret_cast<unsigned*>(cnt)[i] = 0;
+        __syncthreads();
+        const unsigned* sv = kv + src * cap;
+        const unsigned short* si = ki + src * cap;
+        unsigned ev[RS_ROUNDS], ei[RS_ROUNDS], erank[RS_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const int i = r * 1024 + tid;
+            const bool ok = r < rounds && i < cntv;                            // wave-uniform except in the last partial wave
+            ev[r] = ok ? sv[i] : 0u, ei[r] = ok ? si[i] : 0u;
+            const unsigned d = (ev[r] >> shift) & ((1u << DB) - 1u);
+            unsigned long long peers = __ballot(ok);
+#pragma unroll
+            for (int bit = 0; bit < DB; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            erank[r] = (unsigned)__popcll(peers & lt);
+            if (ok && erank[r] == 0) cnt[(d * rounds + r) * 16 + wid] = (unsigned short)__popcll(peers);
         }
+        __syncthreads();
+        // ---- exclusive scan of cnt (digit-major): thread t owns ncnt / 1024 consecutive entries -------------------------------------
+        {
+            const int per = ncnt >> 10;
+            unsigned sum = 0;
+            for (int q = 0; q < per; ++q) sum += cnt[tid * per + q];
+            unsigned inc = sum;                                                // inclusive scan over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = (unsigned)__shfl_up((int)inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) wsum[wid] = inc;
+            __syncthreads();
+            unsigned base = inc - sum;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) base += w < wid ? wsum[w] : 0u;
+            for (int q = 0; q < per; ++q) {
+                const unsigned c = cnt[tid * per + q];
+                cnt[tid * per + q] = (unsigned short)base, base += c;
+            }
+        }
+        __syncthreads();
+        unsigned* dv = kv + (src ^ 1) * cap;
+        unsigned short* di = ki + (src ^ 1) * cap;
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const int i = r * 1024 + tid;
+            if (r < rounds && i < cntv) {
+                const unsigned d = (ev[r] >> shift) & ((1u << DB) - 1u);
+                const unsigned pos = cnt[(d * rounds + r) * 16 + wid] + erank[r];
+                dv[pos] = ev[r], di[pos] = (unsigned short)ei[r];
+            }
+        }
+        src ^= 1;
+        __syncthreads();
     }
+    const unsigned short* so = ki + src * cap;
+    for (int i = tid; i < cntv; i += 1024) {
+        const int a = so[i];
+        const float off = (float)ccls[(size_t)n * A + a] * 7680.0f;
+        const float* bx = cbox + ((size_t)n * A + a) * 4;
+        float* o = sbox + ((size_t)n * A + i) * 4;
+        o[0] = bx[0] + off, o[1] = bx[1] + off, o[2] = bx[2] + off, o[3] = bx[3] + off;
+        sidx[(size_t)n * A + i] = a;
+    }
+    if (tid == 0) scount[n] = cntv;
 }
 
 // Greedy class-aware NMS, one workgroup per image (torchvision.ops.nms semantics on the sorted, class-offset
@@ -1695,15 +1752,6 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
                 return AV_OK;
             }
         }
-        // stride-2 3x3 layers with cin a multiple of 32 that did not fit the weight-stationary kernel (cin = 128): chunked LDS kernel
-        if (a.stride == 2 && a.ksz == 3 && a.cin % LT_CK == 0 && op.mt == 4 && a.cout % 64 == 0 && !a.res && !force_direct &&
-            !getenv("AVHOT_CONV_NO_S2LDS")) {
-            const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
-            const size_t lds = (((size_t)17 * 33 * lt_pixb(2) + 15) & ~size_t(15)) + (size_t)64 * (9 * LT_CK * 2 + 32);
-            hipLaunchKernelGGL((conv_lds_kernel<4, 3, 2>), dim3(tiles_x * tiles_y * B, a.cout / 64), dim3(256), lds, st, a, tiles_x, tiles_y);
-            AV_LAUNCH_CHECK();
-            return AV_OK;
-        }
         if (lds_ok && !force_direct) {
             const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
             const int taps = a.ksz * a.ksz;
@@ -1873,9 +1921,10 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(front_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds(7, 8)));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds(8, 7)));
 #define AV_C1_ATTR(KSV) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<2, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<4, KSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
@@ -2023,7 +2072,11 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                            y.dbg_cconf, y.dbg_ccls);
         AV_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, st, y.A, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
+    {
+        const int rounds = (y.A + 1023) / 1024;
+        if (rounds <= 7) hipLaunchKernelGGL(nms_sort_kernel<8>, dim3(B), dim3(1024), rs_lds(rounds, 8), st, y.A, rounds, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
+        else hipLaunchKernelGGL(nms_sort_kernel<7>, dim3(B), dim3(1024), rs_lds(rounds, 7), st, y.A, rounds, conf_thres, y.cbox, y.cconf, y.ccls, y.sbox, y.sidx, y.scount);
+    }
     AV_LAUNCH_CHECK();
     // gain/pad of ultralytics scale_boxes
     const float gain = std::fmin((float)y.H / y.inH, (float)y.W / y.inW);

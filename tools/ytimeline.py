@@ -7,7 +7,9 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, grid_y, workgroup_x, lds_size from kernels order by start").fetchall()
-i0 = [i for i, r in enumerate(rows) if "stem_conv" in r[0]][-1]
+i0 = [i for i, r in enumerate(rows) if "stem_conv" in r[0] or "front_fused" in r[0]][-1]
+if "front_fused" in rows[i0][0]:
+    i0 += 1                               # (the fused front end has no separate preprocess launch before it)
 t0 = rows[i0][1]
 for j, r in enumerate(rows[i0 - 1:]):
     nm = re.sub(r"\(anonymous namespace\)::", "", r[0])
