@@ -47,7 +47,14 @@ struct ConvArgs {
 
 // SiLU with v_rcp_f32 (1 ulp) instead of an IEEE divide: the result is rounded to half anyway, and the epilogue of
 // these small convolutions is as long as their K loop.
-__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// The product is made opaque before it can meet a conversion to half: hipcc 7.2 otherwise folds "multiply, then round to half" into one
+// v_fma_mixlo_f16 (a single rounding) in SOME kernels and keeps v_mul_f32 + v_cvt_f16_f32 (two roundings) in others -- one half-precision ulp
+// apart on 1 element in 15 000, which is what made c2f32_head_kernel differ from the launches it replaces before this line was added.
+__device__ __forceinline__ float silu(float v) {
+    float r = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    asm("" : "+v"(r));
+    return r;
+}
 
 template <int MT, int NT>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
@@ -879,6 +886,296 @@ __global__ void __launch_bounds__(C2F_NTH, 2) c2f16_fused_kernel(C2f16Args a) {
     }
 }
 
+// Fused C2f blocks with 32 hidden channels (the 1/8-resolution map, P3: layer 4 with two bottlenecks and shortcuts, layer 15 with
+// one and none).  Two kernels on 16 x 16 output tiles with a 2-pixel halo, 16 waves per workgroup, every weight matrix they use
+// resident in LDS; with 32 channels a 3x3 tap is exactly one K = 32 MFMA step.
+//   c2f32_head_kernel:             cv1 (1x1 64 -> 64, in place on the patch) -> 3x3 -> 3x3 + shortcut; writes y0 | y1 | y2 into the
+//                                  block's concat buffer (layer 4's first half: three launches in one)
+//   c2f32_tail_kernel<KCAT, RES>:  3x3 -> 3x3 (+ shortcut) on the concat buffer's last 32 channels, then cv2 (1x1 KCAT + 32 -> 64)
+//                                  whose first KCAT input channels come straight from the concat buffer in global memory (no halo:
+//                                  conv1x1_ws_kernel's operand loads) and whose last 32 from this tile through a per-wave LDS detour
+//                                  (layer 4's second half: KCAT 96, shortcut; layer 15 behind its cv1: KCAT 64, no shortcut)
+// Same K steps in the same order, same epilogue expressions and the same half roundings as conv1x1_ws_kernel / conv3x3_ws_kernel /
+// conv_lds_kernel: bit-identical outputs (tests/test_gpu_yolo.py: fused == separate launches); positions outside the image hold
+// zeros (the 3x3 convolutions' padding).  Layer 4: 6 launches, 107 us -> 2; layer 15: 4 launches -> 2.
+struct C2f32Args {
+    const half_t* in;  int in_cs, in_coff;           // head: cv1's input (64 ch); tail: the pair's input = concat channels [KCAT - 32, KCAT)
+    half_t* cat;       int cat_cs, cat_coff;         // the block's concat buffer (head: written; tail: cv2's first KCAT channels)
+    half_t* out;       int out_cs, out_coff;         // tail: cv2's output (64 ch)
+    int H, W, tiles_x, tiles_y, n_tiles;
+    const half_t *w_cv1, *w_b1, *w_b2, *w_cv2;
+    const float *bs_cv1, *bs_b1, *bs_b2, *bs_cv2;
+    int k1, kb, kc;                                  // global row strides of cv1, the 3x3 layers, cv2
+};
+constexpr int F32_NW = 16, F32_NTH = F32_NW * 64, F32_XW = 20, F32_TW = 18, F32_PS = 96, F32_WBS = 608;      // strides = 32 mod 64 bytes
+constexpr int F32H_XS = 160, F32H_W1S = 160;                                                                      // head: 64-channel patch / cv1 rows
+constexpr int F32H_OFF_T1 = 400 * F32H_XS, F32H_OFF_W1 = F32H_OFF_T1 + 324 * F32_PS, F32H_OFF_WB1 = F32H_OFF_W1 + 64 * F32H_W1S,
+              F32H_OFF_WB2 = F32H_OFF_WB1 + 32 * F32_WBS, F32H_LDS = F32H_OFF_WB2 + 32 * F32_WBS;
+constexpr int f32t_w2s(int kcat) { return ws_stride((kcat + 32) * 2); }
+constexpr int F32T_OFF_T1 = 400 * F32_PS, F32T_OFF_WB1 = F32T_OFF_T1 + 324 * F32_PS, F32T_OFF_WB2 = F32T_OFF_WB1 + 32 * F32_WBS,
+              F32T_OFF_W2 = F32T_OFF_WB2 + 32 * F32_WBS;
+constexpr int f32t_lds(int kcat) { return F32T_OFF_W2 + 64 * f32t_w2s(kcat) + F32_NW * 16 * F32_PS; }
+static_assert(F32H_LDS <= 160 * 1024 && f32t_lds(96) <= 160 * 1024, "one workgroup per CU");
+
+// the two 3x3 layers' weights: global rows [tap][32] -> LDS rows of F32_WBS bytes
+__device__ __forceinline__ void f32_load_pair_weights(const C2f32Args& a, unsigned char* WB1, unsigned char* WB2, int tid) {
+    for (int i = tid; i < 32 * 36; i += F32_NTH) {
+        const int row = i / 36, piece = i - row * 36;
+        *reinterpret_cast<uint4*>(WB1 + row * F32_WBS + piece * 16) = *reinterpret_cast<const uint4*>(a.w_b1 + (size_t)row * a.kb + piece * 8);
+        *reinterpret_cast<uint4*>(WB2 + row * F32_WBS + piece * 16) = *reinterpret_cast<const uint4*>(a.w_b2 + (size_t)row * a.kb + piece * 8);
+    }
+}
+
+// first 3x3 of the pair: 18 x 18 outputs (the second 3x3's input incl. halo) in 21 groups of 16, from channels [coff, coff + 32) of the
+// 20 x 20 patch XP (pixel stride xs bytes) into T1; zero outside the image
+__device__ __forceinline__ void f32_conv_a(const unsigned char* XP, int xs, int coff_bytes, const unsigned char* WB1, unsigned char* T1,
+                                           const float4 (&bs)[2], int oy0, int ox0, int H, int W, int wave, int l15, int h) {
+    for (int g = wave; g < 21; g += F32_NW) {
+        const int q = g * 16 + l15, qq = q < 324 ? q : 323;
+        const int ty = qq / F32_TW, tx = qq - ty * F32_TW;
+        const bool inside = (unsigned)(oy0 - 1 + ty) < (unsigned)H && (unsigned)(ox0 - 1 + tx) < (unsigned)W;
+        half8 bv[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            bv[tap] = *reinterpret_cast<const half8*>(XP + ((ty + tap / 3) * F32_XW + tx + tap % 3) * xs + coff_bytes + 16 * h);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 c[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half8 wv = *reinterpret_cast<const half8*>(WB1 + (mt * 16 + l15) * F32_WBS + tap * 64 + 16 * h);
+                c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c[mt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[4] = {c[mt][0] + bs[mt].x, c[mt][1] + bs[mt].y, c[mt][2] + bs[mt].z, c[mt][3] + bs[mt].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = inside ? silu(v[k]) : 0.f;
+            if (q < 324) *reinterpret_cast<half4*>(T1 + q * F32_PS + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// second 3x3 of the pair for output row r (16 pixels, lane l15 = column): accumulators of the 32 output channels
+__device__ __forceinline__ void f32_conv_b(const unsigned char* T1, const unsigned char* WB2, int r, int l15, int h, f32x4 (&c)[2]) {
+    half8 bv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bv[tap] = *reinterpret_cast<const half8*>(T1 + ((r + tap / 3) * F32_TW + l15 + tap % 3) * F32_PS + 16 * h);
+    __builtin_amdgcn_sched_barrier(0);
+    c[0] = c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const half8 wv = *reinterpret_cast<const half8*>(WB2 + (mt * 16 + l15) * F32_WBS + tap * 64 + 16 * h);
+            c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c[mt], 0, 0, 0);
+        }
+}
+
+__global__ void __launch_bounds__(F32_NTH) c2f32_head_kernel(C2f32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    unsigned char* XY = lsm;                                  // [400][64 ch]: input patch, then cv1's output y0 | y1 in place
+    unsigned char* T1 = lsm + F32H_OFF_T1;                    // [324][32 ch]
+    unsigned char* W1 = lsm + F32H_OFF_W1;                    // cv1 [64][64]
+    unsigned char* WB1 = lsm + F32H_OFF_WB1;
+    unsigned char* WB2 = lsm + F32H_OFF_WB2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    for (int i = tid; i < 64 * 8; i += F32_NTH)
+        *reinterpret_cast<uint4*>(W1 + (i >> 3) * F32H_W1S + (i & 7) * 16) = *reinterpret_cast<const uint4*>(a.w_cv1 + (size_t)(i >> 3) * a.k1 + (i & 7) * 8);
+    f32_load_pair_weights(a, WB1, WB2, tid);
+    float4 bs1[4], bsa[2], bsb[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bs1[mt] = *reinterpret_cast<const float4*>(a.bs_cv1 + mt * 16 + 4 * h);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) bsa[mt] = *reinterpret_cast<const float4*>(a.bs_b1 + mt * 16 + 4 * h), bsb[mt] = *reinterpret_cast<const float4*>(a.bs_b2 + mt * 16 + 4 * h);
+#define F32_USE(b) asm volatile("" ::"v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w))
+    F32_USE(bs1[0]); F32_USE(bs1[1]); F32_USE(bs1[2]); F32_USE(bs1[3]); F32_USE(bsa[0]); F32_USE(bsa[1]); F32_USE(bsb[0]); F32_USE(bsb[1]);
+    constexpr int NP = (400 * 8 + F32_NTH - 1) / F32_NTH;         // 16-byte pieces of the 64-channel patch per thread
+    uint4 pv[NP];
+    auto origin = [&](int t, int& n, int& oy0, int& ox0) {
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
+    };
+    auto gload = [&](int t) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * F32_NTH, pix = i >> 3, part = i & 7;
+            const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            pv[k] = make_uint4(0, 0, 0, 0);
+            if (i < 3200 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < a.n_tiles) gload(t);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+        __syncthreads();                                       // previous tile done with XY / T1 (and the weights are in)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * F32_NTH;
+            if (i < 3200) *reinterpret_cast<uint4*>(XY + (i >> 3) * F32H_XS + (i & 7) * 16) = pv[k];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);
+        // ---- cv1 in place: 25 groups of 16 patch pixels, two K steps, four channel tiles --------------------------------------------------
+        for (int g = wave; g < 25; g += F32_NW) {
+            const int pix = g * 16 + l15;
+            const int py = pix / F32_XW, px = pix - py * F32_XW;
+            const bool inside = (unsigned)(oy0 - 2 + py) < (unsigned)a.H && (unsigned)(ox0 - 2 + px) < (unsigned)a.W;
+            unsigned char* xp = XY + pix * F32H_XS;
+            const half8 b0 = *reinterpret_cast<const half8*>(xp + 16 * h), b1 = *reinterpret_cast<const half8*>(xp + 64 + 16 * h);
+            f32x4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 w0 = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * F32H_W1S + 16 * h);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 w1 = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * F32H_W1S + 64 + 16 * h);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b1, acc[mt], 0, 0, 0);
+            }
+            // the MFMAs have read all 64 channels of these 16 pixels (every lane of the wave): in place is safe
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float v[4] = {acc[mt][0] + bs1[mt].x, acc[mt][1] + bs1[mt].y, acc[mt][2] + bs1[mt].z, acc[mt][3] + bs1[mt].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = inside ? silu(v[q]) : 0.f;
+                *reinterpret_cast<half4*>(xp + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        // ---- y0 | y1 of the tile's own pixels -> concat channels [0, 64) -------------------------------------------------------------------
+        for (int i = tid; i < 256 * 8; i += F32_NTH) {
+            const int pix = i >> 3, part = i & 7, r = pix >> 4, cx = pix & 15, oy = oy0 + r, ox = ox0 + cx;
+            if (oy < a.H && ox < a.W)
+                *reinterpret_cast<uint4*>(a.cat + ((size_t)(n * a.H + oy) * a.W + ox) * a.cat_cs + a.cat_coff + part * 8) =
+                    *reinterpret_cast<const uint4*>(XY + ((r + 2) * F32_XW + cx + 2) * F32H_XS + part * 16);
+        }
+        f32_conv_a(XY, F32H_XS, 64, WB1, T1, bsa, oy0, ox0, a.H, a.W, wave, l15, h);      // on y1 = channels 32..63
+        __syncthreads();
+        {   // ---- second 3x3 + shortcut -> y2 = concat channels [64, 96): wave = output row -------------------------------------------------
+            const int r = wave;
+            f32x4 c[2];
+            f32_conv_b(T1, WB2, r, l15, h, c);
+            const unsigned char* xp = XY + ((r + 2) * F32_XW + l15 + 2) * F32H_XS;
+            const int oy = oy0 + r, ox = ox0 + l15;
+            half_t* op = a.cat + ((size_t)(n * a.H + oy) * a.W + ox) * a.cat_cs + a.cat_coff + 64 + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const half4 rr = *reinterpret_cast<const half4*>(xp + 64 + mt * 32 + 8 * h);          // the shortcut: y1
+                float v[4] = {c[mt][0] + bsb[mt].x, c[mt][1] + bsb[mt].y, c[mt][2] + bsb[mt].z, c[mt][3] + bsb[mt].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
+                if (oy < a.H && ox < a.W) *reinterpret_cast<half4*>(op + mt * 16) = make_half4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int KCAT, bool SHORTCUT>
+__global__ void __launch_bounds__(F32_NTH) c2f32_tail_kernel(C2f32Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    constexpr int W2S = f32t_w2s(KCAT), NKG = KCAT / 32, OFF_Y = F32T_OFF_W2 + 64 * W2S;
+    unsigned char* XP = lsm;                                  // [400][32 ch]: the pair's input incl. halo
+    unsigned char* T1 = lsm + F32T_OFF_T1;
+    unsigned char* WB1 = lsm + F32T_OFF_WB1;
+    unsigned char* WB2 = lsm + F32T_OFF_WB2;
+    unsigned char* W2 = lsm + F32T_OFF_W2;                    // cv2 [64][KCAT + 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    unsigned char* Y = lsm + OFF_Y + wave * 16 * F32_PS;      // this wave's [16 px][32 ch] detour
+    f32_load_pair_weights(a, WB1, WB2, tid);
+    for (int i = tid; i < 64 * (KCAT + 32) / 8; i += F32_NTH) {
+        const int row = i / ((KCAT + 32) / 8), piece = i - row * ((KCAT + 32) / 8);
+        *reinterpret_cast<uint4*>(W2 + row * W2S + piece * 16) = *reinterpret_cast<const uint4*>(a.w_cv2 + (size_t)row * a.kc + piece * 8);
+    }
+    float4 bsa[2], bsb[2], bs2[4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) bsa[mt] = *reinterpret_cast<const float4*>(a.bs_b1 + mt * 16 + 4 * h), bsb[mt] = *reinterpret_cast<const float4*>(a.bs_b2 + mt * 16 + 4 * h);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bs2[mt] = *reinterpret_cast<const float4*>(a.bs_cv2 + mt * 16 + 4 * h);
+    F32_USE(bsa[0]); F32_USE(bsa[1]); F32_USE(bsb[0]); F32_USE(bsb[1]); F32_USE(bs2[0]); F32_USE(bs2[1]); F32_USE(bs2[2]); F32_USE(bs2[3]);
+#undef F32_USE
+    constexpr int NP = (400 * 4 + F32_NTH - 1) / F32_NTH;
+    uint4 pv[NP];
+    auto origin = [&](int t, int& n, int& oy0, int& ox0) {
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
+    };
+    auto gload = [&](int t) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * F32_NTH, pix = i >> 2, part = i & 3;
+            const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            pv[k] = make_uint4(0, 0, 0, 0);
+            if (i < 1600 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
+        }
+    };
+    int t = blockIdx.x;
+    if (t < a.n_tiles) gload(t);
+    for (; t < a.n_tiles; t += gridDim.x) {
+        int n, oy0, ox0;
+        origin(t, n, oy0, ox0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i = tid + k * F32_NTH;
+            if (i < 1600) *reinterpret_cast<uint4*>(XP + (i >> 2) * F32_PS + (i & 3) * 16) = pv[k];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);
+        // cv2's operands from the concat buffer (this wave's output row): requested now, used after the two 3x3 layers
+        const int r = wave, oy = oy0 + r, ox = ox0 + l15;
+        const bool ok = oy < a.H && ox < a.W;
+        const size_t pix = ok ? (size_t)(n * a.H + oy) * a.W + ox : 0;             // outside: pixel 0, never stored
+        half8 bc[NKG];
+#pragma unroll
+        for (int k = 0; k < NKG; ++k) bc[k] = *reinterpret_cast<const half8*>(a.cat + pix * a.cat_cs + a.cat_coff + k * 32 + 8 * h);
+        f32_conv_a(XP, F32_PS, 0, WB1, T1, bsa, oy0, ox0, a.H, a.W, wave, l15, h);
+        __syncthreads();
+        f32x4 c[2];
+        f32_conv_b(T1, WB2, r, l15, h, c);
+        const unsigned char* xp = XP + ((r + 2) * F32_XW + l15 + 2) * F32_PS;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float v[4] = {c[mt][0] + bsb[mt].x, c[mt][1] + bsb[mt].y, c[mt][2] + bsb[mt].z, c[mt][3] + bsb[mt].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+            if (SHORTCUT) {
+                const half4 rr = *reinterpret_cast<const half4*>(xp + mt * 32 + 8 * h);
+                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
+            }
+            *reinterpret_cast<half4*>(Y + l15 * F32_PS + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+        }
+        const half8 by = *reinterpret_cast<const half8*>(Y + l15 * F32_PS + 16 * h);    // same wave wrote it: LDS operations of a wave complete in order
+        f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int k = 0; k <= NKG; ++k)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 wa = *reinterpret_cast<const half8*>(W2 + (mt * 16 + l15) * W2S + k * 64 + 16 * h);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, k < NKG ? bc[k < NKG ? k : 0] : by, o[mt], 0, 0, 0);
+            }
+        half_t* op = a.out + pix * a.out_cs + a.out_coff + 4 * h;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float v[4] = {o[mt][0] + bs2[mt].x, o[mt][1] + bs2[mt].y, o[mt][2] + bs2[mt].z, o[mt][3] + bs2[mt].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+            if (ok) *reinterpret_cast<half4*>(op + mt * 16) = make_half4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // Stem: 3x3 stride-2 convolution 3 -> 16 channels on the framed NHWC4 input.  K is laid out as [ky][kx 0..3][c 0..3]
 // (kx = 3 and c = 3 carry zero weights; 48 -> 64): an 8-element B operand is then two horizontally adjacent input
 // pixels = one aligned 16-byte load (the frame makes column 2*ox + kx even and every load in bounds), and the whole
@@ -1468,7 +1765,7 @@ struct Yolo {
     float gain = 1.f;
     std::vector<Buf> bufs;
     struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; };   // lane 1: internal side stream;
-    // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch; dec 1 / 2: the head's last box /
+    // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch; 2 / 3: 32-channel blocks (c2f32_*); dec 1 / 2: the head's last box /
     // class convolution of level dec_level (its epilogue can do the decode)
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1479,6 +1776,7 @@ struct Yolo {
     hipEvent_t ev_heads = nullptr, ev_decoded = nullptr, ev_tail = nullptr;
     bool defer_tail = false, tail_pending = false;
     bool keep_logits = false;            // test hook: also write the float32 head logits and run decode_kernel on them
+    int dbg_cat = -1;                    // test hook: layer 4's concat buffer (tensor id 40)
     int head_begin = -1;                 // first op of the head (everything before it is one dependency chain)
     std::vector<Op> ops;
     std::vector<void*> allocs;
@@ -1606,6 +1904,8 @@ bool add_c2f(Yolo& y, Slice in, Slice out, int n, bool shortcut) {
     }
     if (!add_conv(y, Slice{cat, 0, (2 + n) * c}, out, 1, 1, true, nullptr, 0, nullptr)) return false;
     if (c == 16 && n == 1 && shortcut && in.c == 32 && out.c == 32) y.ops[first].fuse = 1;
+    if (c == 32 && n == 2 && shortcut && in.c == 64 && out.c == 64) y.ops[first].fuse = 2, y.dbg_cat = cat;        // c2f32_head_kernel + c2f32_tail_kernel<96, true>
+    if (c == 32 && n == 1 && !shortcut && out.c == 64) y.ops[first].fuse = 3;                      // cv1 as it is + c2f32_tail_kernel<64, false>
     return true;
 }
 
@@ -1902,6 +2202,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     y.named = {{0, Slice{x0, 0, 3}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
                {6, Slice{cat11, 256, 128}}, {8, Slice{b8, 0, 256}}, {9, Slice{cat20, 128, 256}}, {12, Slice{cat17, 64, 128}},
                {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}};
+    if (y.dbg_cat >= 0) y.named.push_back({40, Slice{y.dbg_cat, 0, y.bufs[y.dbg_cat].C}});
     y.wsrc = nullptr;
     if (!ok) {
         av_yolo_destroy(h);
@@ -1923,6 +2224,9 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f16_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2F_LDS));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(front_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f32_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32H_LDS));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f32_tail_kernel<96, true>), hipFuncAttributeMaxDynamicSharedMemorySize, f32t_lds(96)));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(c2f32_tail_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, f32t_lds(64)));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds(7, 8)));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds(8, 7)));
 #define AV_C1_ATTR(KSV) \
@@ -2044,6 +2348,50 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             AV_LAUNCH_CHECK();
             oi += 3;
             continue;
+        }
+        if ((op.fuse == 2 || op.fuse == 3) && !force_direct && !getenv("AVHOT_YOLO_NO_FUSE") && !getenv("AVHOT_CONV_NO_WS")) {
+            const ConvArgs& c1 = op.ca;
+            const int np = op.fuse == 2 ? 2 : 1;                                   // bottleneck pairs in the block
+            const ConvArgs& c2 = y.ops[oi + 1 + 2 * np].ca;
+            C2f32Args fa{};
+            fa.H = c1.H, fa.W = c1.W, fa.tiles_x = (c1.W + 15) / 16, fa.tiles_y = (c1.H + 15) / 16, fa.n_tiles = fa.tiles_x * fa.tiles_y * B;
+            fa.cat = c1.out, fa.cat_cs = c1.out_cs, fa.cat_coff = c1.out_coff;
+            const dim3 grid((unsigned)std::min(fa.n_tiles, 256));
+            bool shapes = c2.kpad == 32 * (np + 2) && y.ops[oi + 1].ca.kpad == 288 && c2.in == c1.out && c2.in_coff == c1.out_coff && c2.in_cs == c1.out_cs;
+            if (op.fuse == 2) shapes = shapes && c1.kpad == 64;
+            if (shapes) {
+                const char* dbg = getenv("AVHOT_C2F32_DBG");
+                if (op.fuse == 2 && dbg && dbg[0] == '1') {
+                    for (int q = 0; q < 3; ++q) { const int rc = launch_op(y, y.ops[oi + q], st_main, B, force_direct); if (rc != AV_OK) return rc; }
+                } else
+                if (op.fuse == 2) {                                                  // cv1 + first pair
+                    const ConvArgs &b1 = y.ops[oi + 1].ca, &b2 = y.ops[oi + 2].ca;
+                    fa.in = c1.in, fa.in_cs = c1.in_cs, fa.in_coff = c1.in_coff;
+                    fa.w_cv1 = c1.wgt, fa.bs_cv1 = c1.bias, fa.k1 = c1.kpad;
+                    fa.w_b1 = b1.wgt, fa.w_b2 = b2.wgt, fa.bs_b1 = b1.bias, fa.bs_b2 = b2.bias, fa.kb = b1.kpad;
+                    hipLaunchKernelGGL(c2f32_head_kernel, grid, dim3(F32_NTH), F32H_LDS, st_main, fa);
+                    AV_LAUNCH_CHECK();
+                } else {
+                    const int rc = launch_op(y, op, st_main, B, force_direct);       // cv1 keeps its own launch (cin 192: no halo recompute)
+                    if (rc != AV_OK) return rc;
+                }
+                if (op.fuse == 2 && dbg && dbg[0] == '3') { const int rc = launch_op(y, y.ops[oi], st_main, B, force_direct); if (rc != AV_OK) return rc; }
+                if (op.fuse == 2 && dbg && (dbg[0] == '2' || dbg[0] == '3')) {
+                    for (int q = 3; q < 6; ++q) { const int rc = launch_op(y, y.ops[oi + q], st_main, B, force_direct); if (rc != AV_OK) return rc; }
+                    oi += 5;
+                    continue;
+                }
+                const ConvArgs &b1 = y.ops[oi + 2 * np - 1].ca, &b2 = y.ops[oi + 2 * np].ca;      // the last pair + cv2
+                fa.in = c1.out, fa.in_cs = c1.out_cs, fa.in_coff = c1.out_coff + 32 * np;
+                fa.w_b1 = b1.wgt, fa.w_b2 = b2.wgt, fa.bs_b1 = b1.bias, fa.bs_b2 = b2.bias, fa.kb = b1.kpad;
+                fa.w_cv2 = c2.wgt, fa.bs_cv2 = c2.bias, fa.kc = c2.kpad;
+                fa.out = c2.out, fa.out_cs = c2.out_cs, fa.out_coff = c2.out_coff;
+                if (op.fuse == 2) hipLaunchKernelGGL((c2f32_tail_kernel<96, true>), grid, dim3(F32_NTH), f32t_lds(96), st_main, fa);
+                else hipLaunchKernelGGL((c2f32_tail_kernel<64, false>), grid, dim3(F32_NTH), f32t_lds(64), st_main, fa);
+                AV_LAUNCH_CHECK();
+                oi += 1 + 2 * np;
+                continue;
+            }
         }
         const int rc = launch_op(y, op, (y.side && op.lane) ? y.side : st_main, B, force_direct);
         if (rc != AV_OK) return rc;

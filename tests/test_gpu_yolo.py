@@ -241,17 +241,18 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
 
 
 def test_fused_kernels_are_bit_identical_to_their_separate_launches(setup, monkeypatch):
-    """front_fused_kernel (2:1 letterbox + stem + layer 1 in one launch) and c2f16_fused_kernel (layer 2: cv1, 3x3,
-    3x3 + shortcut, cv2 in one launch) against the separate launches (AVHOT_YOLO_NO_FUSE, read per forward): every
-    element of layer 1's and layer 2's outputs, borders included, on frames with different content, in a batch large
-    enough that persistent workgroups walk more than one tile -- and the detections that come out at the end."""
+    """front_fused_kernel (2:1 letterbox + stem + layer 1 in one launch), c2f16_fused_kernel (layer 2: cv1, 3x3,
+    3x3 + shortcut, cv2 in one launch) and the 32-channel blocks at P3 (layer 4: c2f32_head_kernel + c2f32_tail_kernel for
+    its six convolutions; layer 15: cv1 + c2f32_tail_kernel) against the separate launches (AVHOT_YOLO_NO_FUSE, read per
+    forward): every element of the outputs of layers 1, 2, 4 and 15, borders included, on frames with different content,
+    in a batch large enough that persistent workgroups walk more than one tile -- and the detections at the end."""
     import torch
     Y, R, frame, feats, model, _ = setup
     from oracle.lane_ref import synthetic_frame
     rs = np.random.RandomState(11)
     frames = [frame] + [synthetic_frame(720, 1280, s, f) for s, f in ((6, 40), (2, 77))] + [np.full((720, 1280, 3), 255, np.uint8)]
     frames.append(rs.randint(0, 256, (720, 1280, 3)).astype(np.uint8))          # noise: every pixel of every halo matters
-    frames = frames * 3                                  # 15 images: 1800 front tiles / 900 layer-2 tiles on 512 persistent workgroups
+    frames = frames * 4                                  # 20 images: 2400 front tiles / 1200 layer-2 tiles on 512 persistent workgroups, 300 P3 tiles on 256
     m = Y.YoloV8n("random:0", batch=len(frames))
     m._prepare(720, 1280)
     m._frames.copy_(torch.as_tensor(np.stack(frames)))
@@ -260,13 +261,14 @@ def test_fused_kernels_are_bit_identical_to_their_separate_launches(setup, monke
         m.forward_device(m._frames)
         torch.cuda.synchronize()
         return (m.tensor(1, image=None), m.tensor(2, image=None), m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(),
-                m._conf.cpu().numpy().copy())
+                m._conf.cpu().numpy().copy(), m.tensor(4, image=None), m.tensor(15, image=None))
     fused = run()
     monkeypatch.setenv("AVHOT_YOLO_NO_FUSE", "1")
     unfused = run()
     monkeypatch.delenv("AVHOT_YOLO_NO_FUSE")
     assert fused[0].shape == (len(frames), 96, 160, 32) and fused[0].any() and fused[1].shape == (len(frames), 96, 160, 32) and fused[1].any()
-    for k, name in ((0, "layer 1"), (1, "layer 2")):
+    assert fused[5].shape == (len(frames), 48, 80, 64) and fused[5].any() and fused[6].shape == (len(frames), 48, 80, 64) and fused[6].any()
+    for k, name in ((0, "layer 1"), (1, "layer 2"), (5, "layer 4"), (6, "layer 15")):
         assert np.array_equal(fused[k].view(np.uint32), unfused[k].view(np.uint32)), (name, int((fused[k] != unfused[k]).sum()))
     assert np.array_equal(fused[2], unfused[2]) and np.array_equal(fused[3], unfused[3]) and np.array_equal(fused[4], unfused[4])
     # the keep_logits model (three launches, network input and stem map kept) gives the same layer-1 map as the production path
