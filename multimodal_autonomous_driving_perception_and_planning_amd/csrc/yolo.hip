@@ -907,29 +907,31 @@ struct C2f32Args {
     const float *bs_cv1, *bs_b1, *bs_b2, *bs_cv2;
     int k1, kb, kc;                                  // global row strides of cv1, the 3x3 layers, cv2
 };
-constexpr int F32_NW = 16, F32_NTH = F32_NW * 64, F32_XW = 20, F32_TW = 18, F32_PS = 96, F32_WBS = 608;      // strides = 32 mod 64 bytes
-constexpr int F32H_XS = 160, F32H_W1S = 160;                                                                      // head: 64-channel patch / cv1 rows
-constexpr int F32H_OFF_T1 = 400 * F32H_XS, F32H_OFF_W1 = F32H_OFF_T1 + 324 * F32_PS, F32H_OFF_WB1 = F32H_OFF_W1 + 64 * F32H_W1S,
-              F32H_OFF_WB2 = F32H_OFF_WB1 + 32 * F32_WBS, F32H_LDS = F32H_OFF_WB2 + 32 * F32_WBS;
+constexpr int F32_NW = 8, F32_NTH = F32_NW * 64, F32_XW = 20, F32_TW = 18, F32_PS = 96;      // strides = 32 mod 64 bytes
+constexpr int F32H_XS = 160, F32H_W1S = 160;                                                    // head: 64-channel patch / cv1 rows
+constexpr int F32H_OFF_T1 = 400 * F32H_XS, F32H_OFF_W1 = F32H_OFF_T1 + 324 * F32_PS, F32H_LDS = F32H_OFF_W1 + 64 * F32H_W1S;
 constexpr int f32t_w2s(int kcat) { return ws_stride((kcat + 32) * 2); }
-constexpr int F32T_OFF_T1 = 400 * F32_PS, F32T_OFF_WB1 = F32T_OFF_T1 + 324 * F32_PS, F32T_OFF_WB2 = F32T_OFF_WB1 + 32 * F32_WBS,
-              F32T_OFF_W2 = F32T_OFF_WB2 + 32 * F32_WBS;
+constexpr int F32T_OFF_T1 = 400 * F32_PS, F32T_OFF_W2 = F32T_OFF_T1 + 324 * F32_PS;
 constexpr int f32t_lds(int kcat) { return F32T_OFF_W2 + 64 * f32t_w2s(kcat) + F32_NW * 16 * F32_PS; }
-static_assert(F32H_LDS <= 160 * 1024 && f32t_lds(96) <= 160 * 1024, "one workgroup per CU");
+static_assert(F32H_LDS <= 160 * 1024 && f32t_lds(96) <= 160 * 1024, "fits the LDS");
 
-// the two 3x3 layers' weights: global rows [tap][32] -> LDS rows of F32_WBS bytes
-__device__ __forceinline__ void f32_load_pair_weights(const C2f32Args& a, unsigned char* WB1, unsigned char* WB2, int tid) {
-    for (int i = tid; i < 32 * 36; i += F32_NTH) {
-        const int row = i / 36, piece = i - row * 36;
-        *reinterpret_cast<uint4*>(WB1 + row * F32_WBS + piece * 16) = *reinterpret_cast<const uint4*>(a.w_b1 + (size_t)row * a.kb + piece * 8);
-        *reinterpret_cast<uint4*>(WB2 + row * F32_WBS + piece * 16) = *reinterpret_cast<const uint4*>(a.w_b2 + (size_t)row * a.kb + piece * 8);
-    }
+// A 3x3 layer's 32 x 288 weight matrix as MFMA A operands, held in REGISTERS for the workgroup's whole life: fragment (tap, mt) of
+// a lane = 8 halves of row 16 mt + l15 at k = 32 tap + 8 h; 18 fragments = 72 registers per layer and lane, the whole matrix per wave.
+// With 32 channels a B fragment serves only two MFMAs, so with the weights in LDS (the first version of these kernels) every MFMA
+// cost 1.5 KB of LDS reads -- three times what the CU's 128 bytes per clock deliver in an MFMA's time; from registers only the
+// pixel operands cross the LDS (0.5 KB per MFMA).
+struct F32W { half8 f[18]; };
+__device__ __forceinline__ void f32_load_w(F32W& w, const half_t* g, int kb, int l15, int h) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) w.f[tap * 2 + mt] = *reinterpret_cast<const half8*>(g + (size_t)(mt * 16 + l15) * kb + tap * 32 + 8 * h);
 }
 
 // first 3x3 of the pair: 18 x 18 outputs (the second 3x3's input incl. halo) in 21 groups of 16, from channels [coff, coff + 32) of the
 // 20 x 20 patch XP (pixel stride xs bytes) into T1; zero outside the image
-__device__ __forceinline__ void f32_conv_a(const unsigned char* XP, int xs, int coff_bytes, const unsigned char* WB1, unsigned char* T1,
-                                           const float4 (&bs)[2], int oy0, int ox0, int H, int W, int wave, int l15, int h) {
+__device__ __forceinline__ void f32_conv_a(const unsigned char* XP, int xs, int coff_bytes, const F32W& w, unsigned char* T1,
+                                           const float* bias, int oy0, int ox0, int H, int W, int wave, int l15, int h) {
     for (int g = wave; g < 21; g += F32_NW) {
         const int q = g * 16 + l15, qq = q < 324 ? q : 323;
         const int ty = qq / F32_TW, tx = qq - ty * F32_TW;
@@ -938,18 +940,15 @@ __device__ __forceinline__ void f32_conv_a(const unsigned char* XP, int xs, int 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
             bv[tap] = *reinterpret_cast<const half8*>(XP + ((ty + tap / 3) * F32_XW + tx + tap % 3) * xs + coff_bytes + 16 * h);
-        __builtin_amdgcn_sched_barrier(0);
         f32x4 c[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const half8 wv = *reinterpret_cast<const half8*>(WB1 + (mt * 16 + l15) * F32_WBS + tap * 64 + 16 * h);
-                c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c[mt], 0, 0, 0);
-            }
+            for (int mt = 0; mt < 2; ++mt) c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.f[tap * 2 + mt], bv[tap], c[mt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            float v[4] = {c[mt][0] + bs[mt].x, c[mt][1] + bs[mt].y, c[mt][2] + bs[mt].z, c[mt][3] + bs[mt].w};
+            const float4 bs = *reinterpret_cast<const float4*>(bias + mt * 16 + 4 * h);          // (LDS copy of the bias)
+            float v[4] = {c[mt][0] + bs.x, c[mt][1] + bs.y, c[mt][2] + bs.z, c[mt][3] + bs.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = inside ? silu(v[k]) : 0.f;
             if (q < 324) *reinterpret_cast<half4*>(T1 + q * F32_PS + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
@@ -958,19 +957,24 @@ __device__ __forceinline__ void f32_conv_a(const unsigned char* XP, int xs, int 
 }
 
 // second 3x3 of the pair for output row r (16 pixels, lane l15 = column): accumulators of the 32 output channels
-__device__ __forceinline__ void f32_conv_b(const unsigned char* T1, const unsigned char* WB2, int r, int l15, int h, f32x4 (&c)[2]) {
+__device__ __forceinline__ void f32_conv_b(const unsigned char* T1, const F32W& w, int r, int l15, int h, f32x4 (&c)[2]) {
     half8 bv[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) bv[tap] = *reinterpret_cast<const half8*>(T1 + ((r + tap / 3) * F32_TW + l15 + tap % 3) * F32_PS + 16 * h);
-    __builtin_amdgcn_sched_barrier(0);
     c[0] = c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const half8 wv = *reinterpret_cast<const half8*>(WB2 + (mt * 16 + l15) * F32_WBS + tap * 64 + 16 * h);
-            c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, bv[tap], c[mt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < 2; ++mt) c[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.f[tap * 2 + mt], bv[tap], c[mt], 0, 0, 0);
+}
+
+// biases in LDS (read where they are used: the weight fragments need the registers): [cv1 64 | b1 32 | b2 32 | cv2 64] floats
+constexpr int F32_BIAS_BYTES = 192 * 4;
+__device__ __forceinline__ void f32_load_bias(const C2f32Args& a, float* bl, int tid, bool cv1, bool cv2) {
+    if (tid < 64) bl[tid] = cv1 ? a.bs_cv1[tid] : 0.f;
+    else if (tid < 96) bl[tid] = a.bs_b1[tid - 64];
+    else if (tid < 128) bl[tid] = a.bs_b2[tid - 96];
+    else if (tid < 192) bl[tid] = cv2 ? a.bs_cv2[tid - 128] : 0.f;
 }
 
 __global__ void __launch_bounds__(F32_NTH) c2f32_head_kernel(C2f32Args a) {
@@ -978,75 +982,76 @@ __global__ void __launch_bounds__(F32_NTH) c2f32_head_kernel(C2f32Args a) {
     unsigned char* XY = lsm;                                  // [400][64 ch]: input patch, then cv1's output y0 | y1 in place
     unsigned char* T1 = lsm + F32H_OFF_T1;                    // [324][32 ch]
     unsigned char* W1 = lsm + F32H_OFF_W1;                    // cv1 [64][64]
-    unsigned char* WB1 = lsm + F32H_OFF_WB1;
-    unsigned char* WB2 = lsm + F32H_OFF_WB2;
+    __shared__ __attribute__((aligned(16))) float bl[192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     for (int i = tid; i < 64 * 8; i += F32_NTH)
         *reinterpret_cast<uint4*>(W1 + (i >> 3) * F32H_W1S + (i & 7) * 16) = *reinterpret_cast<const uint4*>(a.w_cv1 + (size_t)(i >> 3) * a.k1 + (i & 7) * 8);
-    f32_load_pair_weights(a, WB1, WB2, tid);
-    float4 bs1[4], bsa[2], bsb[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) bs1[mt] = *reinterpret_cast<const float4*>(a.bs_cv1 + mt * 16 + 4 * h);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bsa[mt] = *reinterpret_cast<const float4*>(a.bs_b1 + mt * 16 + 4 * h), bsb[mt] = *reinterpret_cast<const float4*>(a.bs_b2 + mt * 16 + 4 * h);
-#define F32_USE(b) asm volatile("" ::"v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w))
-    F32_USE(bs1[0]); F32_USE(bs1[1]); F32_USE(bs1[2]); F32_USE(bs1[3]); F32_USE(bsa[0]); F32_USE(bsa[1]); F32_USE(bsb[0]); F32_USE(bsb[1]);
+    f32_load_bias(a, bl, tid, true, false);
+    F32W wa, wb;
+    f32_load_w(wa, a.w_b1, a.kb, l15, h);
+    f32_load_w(wb, a.w_b2, a.kb, l15, h);
     constexpr int NP = (400 * 8 + F32_NTH - 1) / F32_NTH;         // 16-byte pieces of the 64-channel patch per thread
-    uint4 pv[NP];
     auto origin = [&](int t, int& n, int& oy0, int& ox0) {
         const int tx = t % a.tiles_x, r = t / a.tiles_x;
         n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
     };
-    auto gload = [&](int t) {
-        int n, oy0, ox0;
-        origin(t, n, oy0, ox0);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * F32_NTH, pix = i >> 3, part = i & 7;
-            const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-            pv[k] = make_uint4(0, 0, 0, 0);
-            if (i < 3200 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
-        }
-    };
-    int t = blockIdx.x;
-    if (t < a.n_tiles) gload(t);
-    for (; t < a.n_tiles; t += gridDim.x) {
+    for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();                                       // previous tile done with XY / T1 (and the weights are in)
+        {   // the patch: all loads first, then the LDS stores (the weight fragments leave no registers to prefetch the next tile's patch)
+            uint4 pv[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * F32_NTH;
-            if (i < 3200) *reinterpret_cast<uint4*>(XY + (i >> 3) * F32H_XS + (i & 7) * 16) = pv[k];
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * F32_NTH, pix = i >> 3, part = i & 7;
+                const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+                pv[k] = make_uint4(0, 0, 0, 0);
+                if (i < 3200 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * F32_NTH;
+                if (i < 3200) *reinterpret_cast<uint4*>(XY + (i >> 3) * F32H_XS + (i & 7) * 16) = pv[k];
+            }
         }
         __syncthreads();
-        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);
-        // ---- cv1 in place: 25 groups of 16 patch pixels, two K steps, four channel tiles --------------------------------------------------
-        for (int g = wave; g < 25; g += F32_NW) {
-            const int pix = g * 16 + l15;
-            const int py = pix / F32_XW, px = pix - py * F32_XW;
-            const bool inside = (unsigned)(oy0 - 2 + py) < (unsigned)a.H && (unsigned)(ox0 - 2 + px) < (unsigned)a.W;
-            unsigned char* xp = XY + pix * F32H_XS;
-            const half8 b0 = *reinterpret_cast<const half8*>(xp + 16 * h), b1 = *reinterpret_cast<const half8*>(xp + 64 + 16 * h);
-            f32x4 acc[4];
+        // ---- cv1 in place: 25 groups of 16 patch pixels, two at a time per wave (one read of a weight fragment serves both) ------------
+        for (int g0 = 2 * wave; g0 < 25; g0 += 2 * F32_NW) {
+            const bool two = g0 + 1 < 25;
+            unsigned char* xp[2];
+            bool inside[2];
+            half8 b[2][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 w0 = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * F32H_W1S + 16 * h);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int j = 0; j < 2; ++j) {
+                const int pix = (g0 + (two ? j : 0)) * 16 + l15;
+                const int py = pix / F32_XW, px = pix - py * F32_XW;
+                inside[j] = (unsigned)(oy0 - 2 + py) < (unsigned)a.H && (unsigned)(ox0 - 2 + px) < (unsigned)a.W;
+                xp[j] = XY + pix * F32H_XS;
+                b[j][0] = *reinterpret_cast<const half8*>(xp[j] + 16 * h), b[j][1] = *reinterpret_cast<const half8*>(xp[j] + 64 + 16 * h);
             }
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 w1 = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * F32H_W1S + 64 + 16 * h);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b1, acc[mt], 0, 0, 0);
-            }
-            // the MFMAs have read all 64 channels of these 16 pixels (every lane of the wave): in place is safe
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                float v[4] = {acc[mt][0] + bs1[mt].x, acc[mt][1] + bs1[mt].y, acc[mt][2] + bs1[mt].z, acc[mt][3] + bs1[mt].w};
+                for (int mt = 0; mt < 4; ++mt) {
+                    const half8 w = *reinterpret_cast<const half8*>(W1 + (mt * 16 + l15) * F32H_W1S + k * 64 + 16 * h);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = inside ? silu(v[q]) : 0.f;
-                *reinterpret_cast<half4*>(xp + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+                    for (int j = 0; j < 2; ++j)
+                        acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, b[j][k], k ? acc[j][mt] : f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+            // the MFMAs have read all 64 channels of these pixels (every lane of the wave): in place is safe
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j && !two) break;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float4 bs = *reinterpret_cast<const float4*>(bl + mt * 16 + 4 * h);
+                    float v[4] = {acc[j][mt][0] + bs.x, acc[j][mt][1] + bs.y, acc[j][mt][2] + bs.z, acc[j][mt][3] + bs.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = inside[j] ? silu(v[q]) : 0.f;
+                    *reinterpret_cast<half4*>(xp[j] + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+                }
             }
         }
         __syncthreads();
@@ -1057,19 +1062,20 @@ __global__ void __launch_bounds__(F32_NTH) c2f32_head_kernel(C2f32Args a) {
                 *reinterpret_cast<uint4*>(a.cat + ((size_t)(n * a.H + oy) * a.W + ox) * a.cat_cs + a.cat_coff + part * 8) =
                     *reinterpret_cast<const uint4*>(XY + ((r + 2) * F32_XW + cx + 2) * F32H_XS + part * 16);
         }
-        f32_conv_a(XY, F32H_XS, 64, WB1, T1, bsa, oy0, ox0, a.H, a.W, wave, l15, h);      // on y1 = channels 32..63
+        f32_conv_a(XY, F32H_XS, 64, wa, T1, bl + 64, oy0, ox0, a.H, a.W, wave, l15, h);      // on y1 = channels 32..63
         __syncthreads();
-        {   // ---- second 3x3 + shortcut -> y2 = concat channels [64, 96): wave = output row -------------------------------------------------
-            const int r = wave;
+        // ---- second 3x3 + shortcut -> y2 = concat channels [64, 96): two output rows per wave ----------------------------------------------
+        for (int r = wave; r < 16; r += F32_NW) {
             f32x4 c[2];
-            f32_conv_b(T1, WB2, r, l15, h, c);
+            f32_conv_b(T1, wb, r, l15, h, c);
             const unsigned char* xp = XY + ((r + 2) * F32_XW + l15 + 2) * F32H_XS;
             const int oy = oy0 + r, ox = ox0 + l15;
             half_t* op = a.cat + ((size_t)(n * a.H + oy) * a.W + ox) * a.cat_cs + a.cat_coff + 64 + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const half4 rr = *reinterpret_cast<const half4*>(xp + 64 + mt * 32 + 8 * h);          // the shortcut: y1
-                float v[4] = {c[mt][0] + bsb[mt].x, c[mt][1] + bsb[mt].y, c[mt][2] + bsb[mt].z, c[mt][3] + bsb[mt].w};
+                const float4 bs = *reinterpret_cast<const float4*>(bl + 96 + mt * 16 + 4 * h);
+                float v[4] = {c[mt][0] + bs.x, c[mt][1] + bs.y, c[mt][2] + bs.z, c[mt][3] + bs.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
                 v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
@@ -1085,93 +1091,87 @@ __global__ void __launch_bounds__(F32_NTH) c2f32_tail_kernel(C2f32Args a) {
     constexpr int W2S = f32t_w2s(KCAT), NKG = KCAT / 32, OFF_Y = F32T_OFF_W2 + 64 * W2S;
     unsigned char* XP = lsm;                                  // [400][32 ch]: the pair's input incl. halo
     unsigned char* T1 = lsm + F32T_OFF_T1;
-    unsigned char* WB1 = lsm + F32T_OFF_WB1;
-    unsigned char* WB2 = lsm + F32T_OFF_WB2;
     unsigned char* W2 = lsm + F32T_OFF_W2;                    // cv2 [64][KCAT + 32]
+    __shared__ __attribute__((aligned(16))) float bl[192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
     unsigned char* Y = lsm + OFF_Y + wave * 16 * F32_PS;      // this wave's [16 px][32 ch] detour
-    f32_load_pair_weights(a, WB1, WB2, tid);
     for (int i = tid; i < 64 * (KCAT + 32) / 8; i += F32_NTH) {
         const int row = i / ((KCAT + 32) / 8), piece = i - row * ((KCAT + 32) / 8);
         *reinterpret_cast<uint4*>(W2 + row * W2S + piece * 16) = *reinterpret_cast<const uint4*>(a.w_cv2 + (size_t)row * a.kc + piece * 8);
     }
-    float4 bsa[2], bsb[2], bs2[4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bsa[mt] = *reinterpret_cast<const float4*>(a.bs_b1 + mt * 16 + 4 * h), bsb[mt] = *reinterpret_cast<const float4*>(a.bs_b2 + mt * 16 + 4 * h);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) bs2[mt] = *reinterpret_cast<const float4*>(a.bs_cv2 + mt * 16 + 4 * h);
-    F32_USE(bsa[0]); F32_USE(bsa[1]); F32_USE(bsb[0]); F32_USE(bsb[1]); F32_USE(bs2[0]); F32_USE(bs2[1]); F32_USE(bs2[2]); F32_USE(bs2[3]);
-#undef F32_USE
+    f32_load_bias(a, bl, tid, false, true);
+    F32W wa, wb;
+    f32_load_w(wa, a.w_b1, a.kb, l15, h);
+    f32_load_w(wb, a.w_b2, a.kb, l15, h);
     constexpr int NP = (400 * 4 + F32_NTH - 1) / F32_NTH;
-    uint4 pv[NP];
     auto origin = [&](int t, int& n, int& oy0, int& ox0) {
         const int tx = t % a.tiles_x, r = t / a.tiles_x;
         n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
     };
-    auto gload = [&](int t) {
-        int n, oy0, ox0;
-        origin(t, n, oy0, ox0);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * F32_NTH, pix = i >> 2, part = i & 3;
-            const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-            pv[k] = make_uint4(0, 0, 0, 0);
-            if (i < 1600 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
-        }
-    };
-    int t = blockIdx.x;
-    if (t < a.n_tiles) gload(t);
-    for (; t < a.n_tiles; t += gridDim.x) {
+    for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();
+        {
+            uint4 pv[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int i = tid + k * F32_NTH;
-            if (i < 1600) *reinterpret_cast<uint4*>(XP + (i >> 2) * F32_PS + (i & 3) * 16) = pv[k];
-        }
-        __syncthreads();
-        if (t + (int)gridDim.x < a.n_tiles) gload(t + gridDim.x);
-        // cv2's operands from the concat buffer (this wave's output row): requested now, used after the two 3x3 layers
-        const int r = wave, oy = oy0 + r, ox = ox0 + l15;
-        const bool ok = oy < a.H && ox < a.W;
-        const size_t pix = ok ? (size_t)(n * a.H + oy) * a.W + ox : 0;             // outside: pixel 0, never stored
-        half8 bc[NKG];
-#pragma unroll
-        for (int k = 0; k < NKG; ++k) bc[k] = *reinterpret_cast<const half8*>(a.cat + pix * a.cat_cs + a.cat_coff + k * 32 + 8 * h);
-        f32_conv_a(XP, F32_PS, 0, WB1, T1, bsa, oy0, ox0, a.H, a.W, wave, l15, h);
-        __syncthreads();
-        f32x4 c[2];
-        f32_conv_b(T1, WB2, r, l15, h, c);
-        const unsigned char* xp = XP + ((r + 2) * F32_XW + l15 + 2) * F32_PS;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float v[4] = {c[mt][0] + bsb[mt].x, c[mt][1] + bsb[mt].y, c[mt][2] + bsb[mt].z, c[mt][3] + bsb[mt].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
-            if (SHORTCUT) {
-                const half4 rr = *reinterpret_cast<const half4*>(xp + mt * 32 + 8 * h);
-                v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * F32_NTH, pix = i >> 2, part = i & 3;
+                const int py = pix / F32_XW, px = pix - py * F32_XW, iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+                pv[k] = make_uint4(0, 0, 0, 0);
+                if (i < 1600 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    pv[k] = *reinterpret_cast<const uint4*>(a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8);
             }
-            *reinterpret_cast<half4*>(Y + l15 * F32_PS + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
-        }
-        const half8 by = *reinterpret_cast<const half8*>(Y + l15 * F32_PS + 16 * h);    // same wave wrote it: LDS operations of a wave complete in order
-        f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int k = 0; k <= NKG; ++k)
+            for (int k = 0; k < NP; ++k) {
+                const int i = tid + k * F32_NTH;
+                if (i < 1600) *reinterpret_cast<uint4*>(XP + (i >> 2) * F32_PS + (i & 3) * 16) = pv[k];
+            }
+        }
+        __syncthreads();
+        f32_conv_a(XP, F32_PS, 0, wa, T1, bl + 64, oy0, ox0, a.H, a.W, wave, l15, h);
+        __syncthreads();
+        for (int r = wave; r < 16; r += F32_NW) {
+            // cv2's operands from the concat buffer (this output row): requested before the second 3x3, used after it
+            const int oy = oy0 + r, ox = ox0 + l15;
+            const bool ok = oy < a.H && ox < a.W;
+            const size_t pix = ok ? (size_t)(n * a.H + oy) * a.W + ox : 0;             // outside: pixel 0, never stored
+            half8 bc[NKG];
+#pragma unroll
+            for (int k = 0; k < NKG; ++k) bc[k] = *reinterpret_cast<const half8*>(a.cat + pix * a.cat_cs + a.cat_coff + k * 32 + 8 * h);
+            f32x4 c[2];
+            f32_conv_b(T1, wb, r, l15, h, c);
+            const unsigned char* xp = XP + ((r + 2) * F32_XW + l15 + 2) * F32_PS;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float4 bs = *reinterpret_cast<const float4*>(bl + 96 + mt * 16 + 4 * h);
+                float v[4] = {c[mt][0] + bs.x, c[mt][1] + bs.y, c[mt][2] + bs.z, c[mt][3] + bs.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+                if (SHORTCUT) {
+                    const half4 rr = *reinterpret_cast<const half4*>(xp + mt * 32 + 8 * h);
+                    v[0] += h2f(rr.x), v[1] += h2f(rr.y), v[2] += h2f(rr.z), v[3] += h2f(rr.w);
+                }
+                *reinterpret_cast<half4*>(Y + l15 * F32_PS + mt * 32 + 8 * h) = make_half4(v[0], v[1], v[2], v[3]);
+            }
+            const half8 by = *reinterpret_cast<const half8*>(Y + l15 * F32_PS + 16 * h);    // same wave wrote it: LDS operations of a wave complete in order
+            f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k <= NKG; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const half8 wv = *reinterpret_cast<const half8*>(W2 + (mt * 16 + l15) * W2S + k * 64 + 16 * h);
+                    o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, k < NKG ? bc[k < NKG ? k : 0] : by, o[mt], 0, 0, 0);
+                }
+            half_t* op = a.out + pix * a.out_cs + a.out_coff + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const half8 wa = *reinterpret_cast<const half8*>(W2 + (mt * 16 + l15) * W2S + k * 64 + 16 * h);
-                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, k < NKG ? bc[k < NKG ? k : 0] : by, o[mt], 0, 0, 0);
+                const float4 bs = *reinterpret_cast<const float4*>(bl + 128 + mt * 16 + 4 * h);
+                float v[4] = {o[mt][0] + bs.x, o[mt][1] + bs.y, o[mt][2] + bs.z, o[mt][3] + bs.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+                if (ok) *reinterpret_cast<half4*>(op + mt * 16) = make_half4(v[0], v[1], v[2], v[3]);
             }
-        half_t* op = a.out + pix * a.out_cs + a.out_coff + 4 * h;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            float v[4] = {o[mt][0] + bs2[mt].x, o[mt][1] + bs2[mt].y, o[mt][2] + bs2[mt].z, o[mt][3] + bs2[mt].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
-            if (ok) *reinterpret_cast<half4*>(op + mt * 16) = make_half4(v[0], v[1], v[2], v[3]);
         }
     }
 }
