@@ -439,6 +439,23 @@ int av_i420_to_bgr(av_ctx* ctx, av_stream_t stream, int n_frames, int h, int w, 
 int av_synth_frames(av_ctx* ctx, av_stream_t stream, int n_streams, int h, int w, int stream0, int frame,
                     uint8_t* bgr);
 
+/* ---- one launch per time-step (BASELINE config 4, window 1; the reference's per-frame cadence, demo.py:97-120) -----------
+ * av_hot_step = av_simdet_generate + av_tracker_update + av_kf_step + av_planner_plan (no reference path / obstacles) for ONE
+ * frame of every stream, as a single kernel with role-split workgroups that run the stage kernels' own device code: the
+ * results are those of the four calls bit for bit.  Buffers as in the stage calls with n_frames = 1:
+ *   frame_count [S]; det_n [S], det_box [S][dcap][4], det_cls / det_conf [S][dcap], det_status [S] or NULL;
+ *   tracker_state as av_tracker_update; snap [S][tcap] + snap_n [S] (or both NULL); det2trk [S][dcap];
+ *   z [S][4]; kf_state [S][AV_KF_STATE_DOUBLES]; vstate [S][AV_VSTATE_DOUBLES]; plan_state [S][4];
+ *   waypoints [S][C][n][6] or NULL; cost, order [S][C];
+ *   wire: NULL, or [S][av_wire_table_bytes(tcap)] -- every stream's table in the all-gather's wire format (av_pack_tracks with
+ *   n_sel = 1), written by the same launch (needs snap); stream0 / frame0 go into the headers.
+ * Built for tcap 64, dcap 7..8, iou_threshold > 0 (AV_EINVAL otherwise: use the stage calls). */
+int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg, int n_streams, int h,
+                int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n, int32_t* det2trk,
+                const double* z, double* kf_state, double* vstate, double* plan_state, double* waypoints, double* cost,
+                int32_t* order, void* wire, int stream0, int frame0);
+
 #ifdef __cplusplus
 }
 #endif

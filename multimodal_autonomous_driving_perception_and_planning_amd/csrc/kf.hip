@@ -188,15 +188,13 @@ __device__ __forceinline__ void update(Filter& k, const double z[4], double rr) 
         }
 }
 
-__global__ void __launch_bounds__(64) kf_kernel(av_kf_cfg cfg, int n_streams, int n_frames,
+// the dense filter of one stream (one lane)
+__device__ __forceinline__ void kf_dense_stream(const av_kf_cfg& cfg, int s, int n_frames,
                                                 const double* __restrict__ z, const uint8_t* __restrict__ mode,
                                                 double* __restrict__ kf_state, double* __restrict__ out_state,
-                                                double* __restrict__ plan_state, int only_flagged) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams) return;
+                                                double* __restrict__ plan_state) {
     Filter k;
     double* st = kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
-    if (only_flagged && st[45] == 0.0) return;       // handled by kf_axis_kernel
 #pragma unroll
     for (int i = 0; i < 6; ++i) k.x[i] = st[i];
 #pragma unroll
@@ -236,6 +234,16 @@ __global__ void __launch_bounds__(64) kf_kernel(av_kf_cfg cfg, int n_streams, in
 #pragma unroll
         for (int c = 0; c < 6; ++c) st[6 + r * 6 + c] = k.P[r][c];
     st[42] = k.prev_heading, st[43] = k.prev_speed, st[44] = k.time;
+}
+
+__global__ void __launch_bounds__(64) kf_kernel(av_kf_cfg cfg, int n_streams, int n_frames,
+                                                const double* __restrict__ z, const uint8_t* __restrict__ mode,
+                                                double* __restrict__ kf_state, double* __restrict__ out_state,
+                                                double* __restrict__ plan_state, int only_flagged) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    if (only_flagged && kf_state[(size_t)s * AV_KF_STATE_DOUBLES + 45] == 0.0) return;       // handled by kf_axis_kernel
+    kf_dense_stream(cfg, s, n_frames, z, mode, kf_state, out_state, plan_state);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -317,14 +325,14 @@ __device__ __forceinline__ void axis_update(Axis& a, double zp, double zv, doubl
 constexpr int KF_BATCH = 64;
 constexpr int RAW = 12;   // per frame: px py vx vy vxp vyp Ppos_x Ppos_y Pvel_x Pvel_y time mode
 
-__global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames, const double* __restrict__ z,
-                                                     const uint8_t* __restrict__ mode, double* __restrict__ kf_state,
-                                                     double* __restrict__ out_state, double* __restrict__ plan_state) {
+// one stream by one wave (a device function of the stream index: kf_axis_kernel runs it with s = blockIdx.x, the fused time-step
+// kernel of step.hip in the first wave of a planner workgroup).  Returns false when the stream is flagged for the dense filter.
+__device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames, const double* __restrict__ z,
+                                             const uint8_t* __restrict__ mode, double* __restrict__ kf_state,
+                                             double* __restrict__ out_state, double* __restrict__ plan_state, const int s, const int lane) {
     __shared__ __attribute__((aligned(16))) double zl[KF_BATCH][4];
     __shared__ __attribute__((aligned(16))) double raw[KF_BATCH][RAW];
     __shared__ int ml[KF_BATCH];
-    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of throughput kernels on the same SIMD
-    const int s = blockIdx.x, lane = threadIdx.x;
     double* st = kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
 
     // separability check (uniform result): 18 cross-axis entries must be exact zeros
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames
     }
     if (__ballot(bad) != 0ull) {
         if (lane == 0) st[45] = 1.0;
-        return;
+        return false;
     }
     const int ax = lane & 1;                       // lanes >= 2 mirror lanes 0/1 (results unused)
     Axis a;
@@ -467,6 +475,14 @@ __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames
             for (int c = 0; c < 3; ++c) st[6 + (2 * r + ax) * 6 + (2 * c + ax)] = a.p[r][c];
         if (lane == 0) st[42] = carry_h, st[43] = carry_sp, st[44] = time;
     }
+    return true;
+}
+
+__global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames, const double* __restrict__ z,
+                                                     const uint8_t* __restrict__ mode, double* __restrict__ kf_state,
+                                                     double* __restrict__ out_state, double* __restrict__ plan_state) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of throughput kernels on the same SIMD
+    kf_axis_body(cfg, n_frames, z, mode, kf_state, out_state, plan_state, blockIdx.x, threadIdx.x);
 }
 
 __global__ void kf_reset_kernel(int n_streams, double* kf_state) {
@@ -478,6 +494,8 @@ __global__ void kf_reset_kernel(int n_streams, double* kf_state) {
 }
 
 }  // namespace
+
+#ifndef AVHOT_DEVICE_ONLY      // (step.hip includes this file for its device code only)
 
 extern "C" {
 
@@ -504,3 +522,5 @@ int av_kf_step(av_ctx* ctx, av_stream_t stream, const av_kf_cfg* cfg, int n_stre
 }
 
 }  // extern "C"
+
+#endif  // AVHOT_DEVICE_ONLY

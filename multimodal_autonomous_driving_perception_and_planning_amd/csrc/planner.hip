@@ -73,9 +73,9 @@ __device__ __forceinline__ double atan2_fast(double y, double x, const double (&
 
 __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
 
-// doubles of dynamic LDS for a given G
-__host__ __device__ inline size_t plan_lds_doubles(int G, int n, int C) {
-    return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + even_up(G * C) + (size_t)4 * n * 6;
+// doubles of dynamic LDS for G start states per workgroup of NW waves
+__host__ __device__ inline size_t plan_lds_doubles(int G, int n, int C, int NW = 4) {
+    return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + even_up(G * C) + (size_t)NW * n * 6;
 }
 
 // Orders this wave's LDS accesses for the compiler.  The hardware executes one wave's DS operations
@@ -86,54 +86,76 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-template <int G>
-__global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states, const double* __restrict__ state,
-                                                      const double* __restrict__ ref, int n_ref,
-                                                      const double* __restrict__ obs, int n_obs,
-                                                      double* __restrict__ wp, double* __restrict__ cost,
-                                                      int32_t* __restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+// The workgroup-cooperative planner for small batches (and n > 64): G consecutive start states f0 .. f0 + G - 1 by a workgroup of
+// NW waves.  A device function, so that the fused time-step kernel (step.hip) runs the very same code after its Kalman step.
+//   phase 1  per (state, speed) pair, dealt to the waves: lanes make the per-waypoint terms in parallel (velocity blend v_i, v_i dt,
+//            the velocity and acceleration cost terms -- the 50 float64 divides of the acceleration used to sit in ONE lane's
+//            sequential loop, 8 of the kernel's 23 us at 64 states), then lane 0 adds them up left to right in the reference's
+//            order: identical bits, a chain of additions only
+//   phase 2  each wave takes whole trajectories; lane = waypoint (positions, tangent heading by atan2_fast, curvature, cost terms;
+//            AoS image assembled in a per-wave LDS tile and streamed out as 16-byte-per-lane stores)
+//   phase 3  stable rank of the C costs (== Python's stable sort, :300)
+template <int G, int NW>
+__device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_states, const double* __restrict__ state,
+                                           const double* __restrict__ ref, int n_ref, const double* __restrict__ obs, int n_obs,
+                                           double* __restrict__ wp, double* __restrict__ cost, int32_t* __restrict__ order, double* sm) {
     const int n = p.n, C = p.C;
     double* vs = sm;                                   // [G][3][n][2]  (v, s)
     double* base = vs + (size_t)G * 3 * n * 2;         // [G][3][3]     S_v, S_a, running(S_v then acc terms)
     double* trig = base + even_up(G * 3 * 3);          // [G][8]        x0 y0 cos sin cos(h+pi/2) sin(h+pi/2) h0
     double* costs = trig + G * 8;                      // [G][C]
-    double* stage_all = costs + even_up(G * C);        // [4][n*6]
+    double* stage_all = costs + even_up(G * C);        // [NW][n*6]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int f0 = blockIdx.x * G;
+    double* stage = stage_all + (size_t)wid * n * 6;
 
     // ---- phase 1 ---------------------------------------------------------------------------------
-    if (tid < G * 3) {
-        const int g = tid / 3, k = tid - g * 3, f = f0 + g;
-        if (f < n_states) {
-            const double v0 = state[(size_t)f * 4 + 3];
-            const double vt = 8.0 + 2.0 * (double)k;          // [8.0, 10.0, 12.0]  (:280)
-            const double dv = vt - v0;
-            double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
-            double s = 0.0, sv = 0.0;
-            for (int i = 0; i < n; ++i) {
-                const double v = v0 + dv * p.alpha[i];          // :153-154
-                if (i > 0) s = s + v * p.dt;                    // :157
-                o[2 * i] = v, o[2 * i + 1] = s;
-                const double e = v - 10.0;
-                sv = sv + p.w_vel * (e * e);                    // :236
+    for (int pr = wid; pr < G * 3; pr += NW) {
+        const int g = pr / 3, k = pr - g * 3, f = f0 + g;
+        if (f >= n_states) continue;
+        const double v0 = state[(size_t)f * 4 + 3];
+        const double vt = 8.0 + 2.0 * (double)k;              // [8.0, 10.0, 12.0]  (:280)
+        const double dv = vt - v0;
+        double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
+        double* tv = stage;                                   // [n] v_i dt | [n] velocity cost term | [n] acceleration cost term
+        for (int i = lane; i < n; i += 64) {
+            const double v = v0 + dv * p.alpha[i];            // :153-154
+            o[2 * i] = v;
+            tv[i] = v * p.dt;
+            const double e = v - 10.0;
+            tv[n + i] = p.w_vel * (e * e);                    // :236
+            double term = 0.0;
+            if (i > 0) {                                      // (used below only where dtd[i] > 0, like the reference's test)
+                const double vp = v0 + dv * p.alpha[i - 1];
+                const double a = (v - vp) / p.dtd[i];
+                term = p.w_acc * (a * a);                     // :244
+            }
+            tv[2 * n + i] = term;
+        }
+        wave_lds_fence();
+        if (lane == 0) {
+            double sacc = 0.0, sv = 0.0;
+            o[1] = 0.0;
+            sv = sv + tv[n];
+            for (int i = 1; i < n; ++i) {
+                sacc = sacc + tv[i];                          // :157
+                o[2 * i + 1] = sacc;
+                sv = sv + tv[n + i];
             }
             double run = sv, sa = 0.0;
             for (int i = 1; i < n; ++i) {
-                const double dtt = p.dtd[i];
-                if (dtt > 0.0) {
-                    const double a = (o[2 * i] - o[2 * (i - 1)]) / dtt;
-                    const double term = p.w_acc * (a * a);      // :244
-                    run = run + term;
-                    sa = sa + term;
+                if (p.dtd[i] > 0.0) {
+                    const double term = tv[2 * n + i];
+                    run = run + term, sa = sa + term;
                 }
             }
             double* b = base + (g * 3 + k) * 3;
             b[0] = sv, b[1] = sa, b[2] = run;
         }
-    } else if (tid >= 64 && tid < 64 + G) {
-        const int g = tid - 64, f = f0 + g;
+        wave_lds_fence();
+    }
+    if (tid < G) {
+        const int g = tid, f = f0 + g;
         if (f < n_states) {
             const double h0 = state[(size_t)f * 4 + 2];
             const double hp = h0 + 1.5707963267948966;           // heading0 + np.pi/2  (:179)
@@ -145,8 +167,7 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
     __syncthreads();
 
     // ---- phase 2 ---------------------------------------------------------------------------------
-    double* stage = stage_all + (size_t)wid * n * 6;
-    for (int j = wid; j < G * C; j += 4) {
+    for (int j = wid; j < G * C; j += NW) {
         const int g = j / C, c = j - g * C, f = f0 + g;
         if (f >= n_states) continue;
         const int li = c / 3, k = c - li * 3;
@@ -165,7 +186,7 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
                 const double s1 = o[2 * i + 3], d1 = df * p.q[i + 1];
                 double x1 = x0 + s1 * cs, y1 = y0 + s1 * sn;
                 x1 = x1 + d1 * c2, y1 = y1 + d1 * s2;
-                hd = atan2(y1 - y, x1 - x);                     // :188
+                hd = atan2_fast(y1 - y, x1 - x, p.atq);         // :188
             }
             double* w = stage + (size_t)i * 6;
             w[0] = x, w[1] = y, w[2] = hd, w[3] = v, w[4] = p.t[i], w[5] = 0.0;
@@ -219,7 +240,7 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
     __syncthreads();
 
     // ---- phase 3: stable ascending rank (:300) -----------------------------------------------------
-    for (int idx = tid; idx < G * C; idx += 256) {
+    for (int idx = tid; idx < G * C; idx += NW * 64) {
         const int g = idx / C, c = idx - g * C, f = f0 + g;
         if (f >= n_states) continue;
         const double* cc = costs + g * C;
@@ -232,6 +253,16 @@ __global__ void __launch_bounds__(256) planner_kernel(PlanParams p, int n_states
         cost[(size_t)f * C + c] = mine;
         order[(size_t)f * C + rank] = c;
     }
+}
+
+template <int G, int NW>
+__global__ void __launch_bounds__(NW * 64) planner_kernel(PlanParams p, int n_states, const double* __restrict__ state,
+                                                          const double* __restrict__ ref, int n_ref,
+                                                          const double* __restrict__ obs, int n_obs,
+                                                          double* __restrict__ wp, double* __restrict__ cost,
+                                                          int32_t* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    plan_block<G, NW>(p, blockIdx.x * G, n_states, state, ref, n_ref, obs, n_obs, wp, cost, order, sm);
 }
 
 // Output ring of planner_wave_kernel: 256 units of 16 B.  It holds at most 63 carried units + one tile of
@@ -582,6 +613,9 @@ static void fill_params(const av_ctx* ctx, PlanParams& p) {
     for (int k = 0; k < 20; ++k) p.atq[k] = ATAN_Q[k];
 }
 
+#ifndef AVHOT_DEVICE_ONLY      // (step.hip includes this file for its device code only)
+
+
 extern "C" {
 
 int av_planner_generate(av_ctx* ctx, av_stream_t stream, int n_traj, const double* state,
@@ -695,18 +729,19 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
         }
     }
     int G = n_states >= 4096 ? 8 : (n_states >= 1024 ? 4 : (n_states >= 512 ? 2 : 1));
-    while (G > 1 && plan_lds_doubles(G, n, C) * 8 > 48 * 1024) G >>= 1;
-    const size_t lds = plan_lds_doubles(G, n, C) * 8;
+    const int NW = G == 1 ? 8 : 4;                      // one state per workgroup: its 3 C trajectories over eight waves
+    while (G > 1 && plan_lds_doubles(G, n, C, NW) * 8 > 48 * 1024) G >>= 1;
+    const size_t lds = plan_lds_doubles(G, n, C, G == 1 ? 8 : 4) * 8;
     AV_REQUIRE(lds <= 64 * 1024, AV_EINVAL, "av_planner_plan: configuration needs %zu B of LDS", lds);
     const int grid = (n_states + G - 1) / G;
-#define AV_PLAN_LAUNCH(GG)                                                                                        \
-    hipLaunchKernelGGL(planner_kernel<GG>, dim3(grid), dim3(256), lds, st, p, n_states, state, ref_path, n_ref,  \
+#define AV_PLAN_LAUNCH(GG, NWV)                                                                                        \
+    hipLaunchKernelGGL((planner_kernel<GG, NWV>), dim3(grid), dim3(NWV * 64), lds, st, p, n_states, state, ref_path, n_ref,  \
                        obstacles, n_obs, waypoints, cost, order)
     switch (G) {
-        case 8: AV_PLAN_LAUNCH(8); break;
-        case 4: AV_PLAN_LAUNCH(4); break;
-        case 2: AV_PLAN_LAUNCH(2); break;
-        default: AV_PLAN_LAUNCH(1); break;
+        case 8: AV_PLAN_LAUNCH(8, 4); break;
+        case 4: AV_PLAN_LAUNCH(4, 4); break;
+        case 2: AV_PLAN_LAUNCH(2, 4); break;
+        default: AV_PLAN_LAUNCH(1, 8); break;
     }
 #undef AV_PLAN_LAUNCH
     AV_LAUNCH_CHECK();
@@ -714,3 +749,5 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
 }
 
 }  // extern "C"
+
+#endif  // AVHOT_DEVICE_ONLY

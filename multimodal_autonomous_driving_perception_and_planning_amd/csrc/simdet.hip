@@ -120,15 +120,13 @@ __global__ void __launch_bounds__(64) simdet_table_kernel(SimRow* __restrict__ t
 
 // thread = (stream, frame).  ADVANCE: the launch holds one frame per stream, so the thread that read the counter
 // also writes it back (no second launch).
+// one frame of one stream (a device function: the fused time-step kernel of step.hip calls it for its stream's single frame)
 template <bool ADVANCE>
-__global__ void __launch_bounds__(64) simdet_kernel(int n_streams, int n_frames, int h, int w, int dcap,
-                                                    int32_t* __restrict__ frame_count, const SimRow* __restrict__ tab,
-                                                    const double* __restrict__ cdf, int32_t* __restrict__ det_n,
-                                                    int32_t* __restrict__ det_box, int32_t* __restrict__ det_cls,
-                                                    double* __restrict__ det_conf, int32_t* __restrict__ status) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)n_streams * n_frames) return;
-    const int s = (int)(gid / n_frames), f = (int)(gid % n_frames);
+__device__ __forceinline__ void simdet_frame(long long gid, int s, int f, int h, int w, int dcap,
+                                             int32_t* __restrict__ frame_count, const SimRow* __restrict__ tab,
+                                             const double* __restrict__ cdf, int32_t* __restrict__ det_n,
+                                             int32_t* __restrict__ det_box, int32_t* __restrict__ det_cls,
+                                             double* __restrict__ det_conf, int32_t* __restrict__ status) {
     const int fc = frame_count[s] + f + 1;                 // detector.py:96 increments before use
     if (ADVANCE) frame_count[s] = fc;
     const SimRow& row = tab[((fc % 1000) + 1000) % 1000];
@@ -174,12 +172,26 @@ __global__ void __launch_bounds__(64) simdet_kernel(int n_streams, int n_frames,
     if (row.overflow && status) atomicOr(&status[s], 1);
 }
 
+template <bool ADVANCE>
+__global__ void __launch_bounds__(64) simdet_kernel(int n_streams, int n_frames, int h, int w, int dcap,
+                                                    int32_t* __restrict__ frame_count, const SimRow* __restrict__ tab,
+                                                    const double* __restrict__ cdf, int32_t* __restrict__ det_n,
+                                                    int32_t* __restrict__ det_box, int32_t* __restrict__ det_cls,
+                                                    double* __restrict__ det_conf, int32_t* __restrict__ status) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n_streams * n_frames) return;
+    simdet_frame<ADVANCE>(gid, (int)(gid / n_frames), (int)(gid % n_frames), h, w, dcap, frame_count, tab, cdf, det_n, det_box, det_cls,
+                          det_conf, status);
+}
+
 __global__ void advance_counter_kernel(int n_streams, int n_frames, int32_t* frame_count) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n_streams) frame_count[s] += n_frames;
 }
 
 }  // namespace
+
+#ifndef AVHOT_DEVICE_ONLY      // (step.hip includes this file for its device code only)
 
 // called by av_ctx_create / av_ctx_destroy (ctx.hip)
 int av_simdet_ctx_init(av_ctx* ctx) {
@@ -216,3 +228,5 @@ extern "C" int av_simdet_generate(av_ctx* ctx, av_stream_t stream, int n_streams
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
+
+#endif  // AVHOT_DEVICE_ONLY

@@ -1,0 +1,129 @@
+// H: one TIME-STEP of the hot loop for every stream in ONE launch (BASELINE config 4: "64 concurrent synthetic streams batched
+// through detector -> tracker -> KF -> planner, hipGraph-captured per-step"; the reference's per-frame cadence, demo.py:97-120).
+//
+// With one frame per stream and launch the four stage kernels are latency chains of a few microseconds each, and a step is
+// their launches: four graph nodes, ~60 us per step of 64 frames, of which ~16 us graph replay and 23 us a planner kernel for 64
+// start states.  Here the step is one kernel with role-split workgroups, every role running the stage kernels' OWN device code
+// (simdet_frame, tracker_body, kf_axis_body / kf_dense_stream, plan_block: this file includes the stage files for their device
+// parts), so the results are those of the separate launches bit for bit (tests/test_gpu_step.py):
+//   workgroups [0, S)      stream s: simulated detections of its next frame (one thread: a 232-byte table row + box arithmetic),
+//                          then the tracker frame on eight replica waves, then -- optionally -- the stream's 32-byte-per-row
+//                          wire table for the all-gather (exchange.hip's format), all from the same workgroup
+//   workgroups [S, 2 S)    stream s: Kalman step in the first wave (axis-separable filter; the dense filter on one lane for a
+//                          stream flagged non-separable), then the 3 C candidate trajectories spread over the workgroup's
+//                          eight waves (plan_block<1, 8>), cost ranking, outputs
+// The two roles of a stream never exchange data (the planner does not consume tracks).
+#define AVHOT_DEVICE_ONLY
+#include "simdet.hip"
+#include "tracker.hip"
+#include "kf.hip"
+#include "planner.hip"
+#undef AVHOT_DEVICE_ONLY
+
+namespace {
+
+struct StepArgs {
+    int S, h, w, dcap, tcap;
+    av_tracker_cfg tcfg;
+    av_kf_cfg kcfg;
+    PlanParams pp;
+    int32_t* frame_count; const SimRow* tab; const double* cdf;
+    int32_t *det_n, *det_box, *det_cls; double* det_conf; int32_t* det_status;
+    unsigned char* trk_state; av_track_row* snap; int32_t* snap_n; int32_t* det2trk;
+    const double* z; double *kf_state, *vstate, *plan_state;
+    double *wp, *cost; int32_t* order;
+    uint8_t* wire; int stream0, frame0;
+};
+
+constexpr int STEP_NW = 8;
+
+__global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < a.S) {
+        const int s = blockIdx.x;
+        if (tid == 0)
+            simdet_frame<true>(s, s, 0, a.h, a.w, a.dcap, a.frame_count, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf, a.det_status);
+        __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0))
+        tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, a.det_n, a.det_box, a.det_cls, a.det_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
+                                        a.det2trk, 1, s, smem);
+        if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
+            __syncthreads();          // the snapshot rows the bookkeeper wave wrote
+            const int r = tid;
+            if (r < a.tcap) {
+                const int n = a.snap_n[s];
+                uint8_t* dst = a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES);
+                if (r == 0) {
+                    av_wire_hdr hd;
+                    hd.n_rows = n < a.tcap ? n : a.tcap, hd.stream = a.stream0 + s, hd.frame = a.frame0, hd.reserved = 0;
+                    *reinterpret_cast<av_wire_hdr*>(dst) = hd;
+                }
+                av_wire_row o;
+                if (r < n) {
+                    const av_track_row in = a.snap[(size_t)s * a.tcap + r];
+                    o.id = in.id;
+                    o.x1 = (int16_t)in.x1, o.y1 = (int16_t)in.y1, o.x2 = (int16_t)in.x2, o.y2 = (int16_t)in.y2;
+                    o.age = in.age, o.hits = in.hits;
+                    o.misses = (uint16_t)(in.misses > 65535 ? 65535 : in.misses);
+                    o.cls = (uint8_t)in.cls, o.flags = (uint8_t)in.flags;
+                    o.conf = (float)in.conf;
+                    o.vx2 = (int16_t)(in.vx * 2.0f), o.vy2 = (int16_t)(in.vy * 2.0f);
+                } else {
+                    o.id = 0, o.x1 = o.y1 = o.x2 = o.y2 = 0, o.age = o.hits = 0, o.misses = 0, o.cls = 0, o.flags = 0, o.conf = 0.0f;
+                    o.vx2 = o.vy2 = 0;
+                }
+                reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = o;
+            }
+        }
+    } else {
+        const int s = blockIdx.x - a.S;
+        if (tid < 64) {
+            const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid);
+            if (!separable && tid == 0) kf_dense_stream(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);
+        }
+        __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
+        plan_block<1, STEP_NW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
+    }
+}
+
+}  // namespace
+
+extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+                           int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                           double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
+                           int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
+                           double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0) {
+    AV_REQUIRE(ctx && tcfg && kcfg && frame_count && det_n && det_box && det_cls && det_conf && tracker_state && z && kf_state &&
+                   vstate && plan_state && cost && order,
+               AV_EINVAL, "av_hot_step: null argument");
+    AV_REQUIRE(n_streams > 0, AV_EINVAL, "av_hot_step: n_streams must be > 0");
+    AV_REQUIRE(ctx->planner_ready && ctx->d_simtab, AV_ESTATE, "av_hot_step: call av_planner_configure first");
+    AV_REQUIRE((snap == nullptr) == (snap_n == nullptr), AV_EINVAL, "av_hot_step: snap and snap_n go together");
+    AV_REQUIRE(!wire || snap, AV_EINVAL, "av_hot_step: the wire tables are made from the snapshot rows");
+    // the shapes the one-launch step is built for; anything else keeps the four stage calls
+    AV_REQUIRE(tcap == 64 && dcap >= 7 && dcap <= 8 && tcfg->iou_threshold > 0.0 && tcfg->trajectory_length >= 1, AV_EINVAL,
+               "av_hot_step: needs tcap 64, dcap 7..8 and iou_threshold > 0 (use the stage calls otherwise)");
+    AV_REQUIRE(h > 0 && w > 121, AV_EINVAL, "av_hot_step: frame %dx%d too small", w, h);
+    StepArgs a{};
+    a.S = n_streams, a.h = h, a.w = w, a.dcap = dcap, a.tcap = tcap;
+    a.tcfg = *tcfg, a.kcfg = *kcfg;
+    fill_params(ctx, a.pp);
+    a.frame_count = frame_count, a.tab = (const SimRow*)ctx->d_simtab, a.cdf = ctx->d_cdf;
+    a.det_n = det_n, a.det_box = det_box, a.det_cls = det_cls, a.det_conf = det_conf, a.det_status = det_status;
+    a.trk_state = (unsigned char*)tracker_state, a.snap = snap, a.snap_n = snap_n, a.det2trk = det2trk;
+    a.z = z, a.kf_state = kf_state, a.vstate = vstate, a.plan_state = plan_state;
+    a.wp = waypoints, a.cost = cost, a.order = order;
+    a.wire = (uint8_t*)wire, a.stream0 = stream0, a.frame0 = frame0;
+    // dynamic LDS: the larger of the tracker's (av_tracker_update's layout for one staged frame, eight replicas) and the planner's
+    const int fc = 1;
+    const size_t chunk_bytes = (size_t)((fc + 3) & ~3) * 4 + (size_t)fc * dcap * 16 + (((size_t)fc * dcap + 1) & ~size_t(1)) * 4 +
+                               (size_t)fc * dcap * 16 + 16;
+    const size_t rep_bytes = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
+    const size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
+    const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, STEP_NW) * 8;
+    const size_t lds = lds_t > lds_p ? lds_t : lds_p;
+    AV_REQUIRE(lds <= 64 * 1024, AV_EINVAL, "av_hot_step: configuration needs %zu B of LDS", lds);
+    hipLaunchKernelGGL(hot_step_kernel, dim3(2 * n_streams), dim3(STEP_NW * 64), lds, as_stream(stream), a);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -85,13 +85,14 @@ __device__ __forceinline__ void lds_sync() {
 
 // DREG > 0: the row's IoU against every detection (dcap <= DREG) is computed once per frame and kept in
 // registers; DREG == 0: generic path for larger dcap (best candidate recomputed when its column is taken).
+// (a device function of the stream index s: tracker_kernel runs it with s = blockIdx.x, the fused time-step kernel of step.hip
+// with its own workgroup-to-stream map; smem = the workgroup's dynamic LDS)
 template <bool MULTIWAVE, int DREG, int REP>
-__global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
+__device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
                                const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
-                               int32_t* __restrict__ det2trk, int chunk_frames) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+                               int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem) {
     constexpr bool REPL = REP > 1;
     static_assert(!(REPL && MULTIWAVE), "replica waves hold the whole table: tcap must be 64");
     static_assert(REP == 1 || REP == 8, "the exchange buffers are laid out for 8 columns");
@@ -119,7 +120,6 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
 
     // a dependent per-frame chain: let these few waves issue ahead of throughput kernels sharing the SIMD
     __builtin_amdgcn_s_setprio(3);
-    const int s = blockIdx.x;
     const int nwaves = (tcap + 63) >> 6;
     const int L = cfg.trajectory_length;
 
@@ -587,6 +587,17 @@ __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n
     if (row == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
 }
 
+template <bool MULTIWAVE, int DREG, int REP>
+__global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
+                               const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
+                               const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
+                               av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
+                               int32_t* __restrict__ det2trk, int chunk_frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tracker_body<MULTIWAVE, DREG, REP>(cfg, n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, state_all, snap, snap_n, det2trk,
+                                       chunk_frames, blockIdx.x, smem);
+}
+
 __global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, unsigned char* state) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
@@ -596,6 +607,8 @@ __global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, uns
 }
 
 }  // namespace
+
+#ifndef AVHOT_DEVICE_ONLY      // (step.hip includes this file for its device code only)
 
 extern "C" {
 
@@ -660,3 +673,5 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
 }
 
 }  // extern "C"
+
+#endif  // AVHOT_DEVICE_ONLY

@@ -21,7 +21,10 @@ from . import _native as nat
 class HotLoop:
     def __init__(self, n_streams=1, window=1, h=720, w=1280, tcap=64, dcap=8, device=0,
                  tracker_kw=None, kf_kw=None, planner_kw=None, keep_waypoints=True, keep_snapshots=True,
-                 ctx=None):
+                 ctx=None, fused_step=None):
+        """fused_step: with window 1, run a time-step as ONE launch (av_hot_step: role-split workgroups running the stage
+        kernels' own device code, same results bit for bit) instead of the four stage launches.  None = whenever the
+        configuration allows it (window 1, tcap 64, dcap 7..8, iou_threshold > 0)."""
         if not torch.cuda.is_available():
             raise RuntimeError("HotLoop needs a HIP device; this package has no CPU path")
         self.S, self.W, self.h, self.w, self.tcap, self.dcap = n_streams, window, h, w, tcap, dcap
@@ -68,6 +71,12 @@ class HotLoop:
         self.order = torch.zeros(S * W, self.n_cand, dtype=i32, device=d)
         self.stream = torch.cuda.Stream(device=d)
         self.graph_id = None
+        can_fuse = window == 1 and tcap == 64 and 7 <= dcap <= 8 and self.tcfg.iou_threshold > 0
+        if fused_step and not can_fuse:
+            raise ValueError("fused_step needs window 1, tcap 64, dcap 7..8 and iou_threshold > 0")
+        self.fused_step = can_fuse if fused_step is None else bool(fused_step)
+        self.wire = None                  # set_wire(): the fused step also writes every stream's table in wire format
+        self._wire_ids = (0, 0)
         self.reset()
 
     # ------------------------------------------------------------------------------------------
@@ -174,9 +183,29 @@ class HotLoop:
                                          nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),
                                          nat.ptr(self.cost), nat.ptr(self.order)))
 
+    def set_wire(self, wire, stream0=0, frame0=0):
+        """Fused step only: `wire` (uint8 device tensor [S, av_wire_table_bytes(tcap)], or None) receives every stream's
+        track table in the all-gather's wire format from the same launch; stream0 / frame0 go into the table headers."""
+        if wire is not None and not (self.fused_step and self.keep_snapshots):
+            raise RuntimeError("set_wire needs the fused step and keep_snapshots=True")
+        self.wire, self._wire_ids = wire, (int(stream0), int(frame0))
+
+    def enqueue_step_fused(self, stream=None):
+        """Window 1: detect + track + Kalman + plan of one frame of every stream as ONE launch."""
+        nat.check(self.L.av_hot_step(self.ctx.handle, stream or self._s, C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h,
+                                     self.w, self.dcap, self.tcap, nat.ptr(self.frame_count), nat.ptr(self.det_n),
+                                     nat.ptr(self.det_box), nat.ptr(self.det_cls), nat.ptr(self.det_conf),
+                                     nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(self.snap), nat.ptr(self.snap_n),
+                                     nat.ptr(self.det2trk), nat.ptr(self.z), nat.ptr(self.kf_state), nat.ptr(self.vstate),
+                                     nat.ptr(self.plan_state), nat.ptr(self.wp), nat.ptr(self.cost), nat.ptr(self.order),
+                                     nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1]))
+
     def enqueue_step(self):
         """One window of the whole loop: fork{detect; track} || {kf; plan}; join.  Detections only feed the
-        tracker, so both sit on the side stream and the Kalman/planner chain starts at once."""
+        tracker, so both sit on the side stream and the Kalman/planner chain starts at once.  With window 1 and
+        fused_step the whole step is one launch instead."""
+        if self.fused_step:
+            return self.enqueue_step_fused()
         h, L, s = self.ctx.handle, self.L, self._s
         nat.check(L.av_fork(h, s))
         self.enqueue_detect(self.ctx.side_stream)
