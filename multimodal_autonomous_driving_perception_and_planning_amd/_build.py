@@ -27,22 +27,30 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(ROOT, "include", "avhot.h"))
-    return max(os.path.getmtime(h) for h in hdrs)
+def _deps_mtime(src, seen=None):
+    """Newest modification time of `src` and of everything it includes from csrc/ or include/ (step.hip includes the stage
+    files themselves, not only headers)."""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return 0.0
+    seen.add(src)
+    m = os.path.getmtime(src)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), flags=re.M):
+        for d in (CSRC, os.path.join(ROOT, "include")):
+            m = max(m, _deps_mtime(os.path.join(d, inc), seen))
+    return m
 
 
 def build(force=False, verbose=True, jobs=None):
     """Compile every csrc/*.hip for gfx950 and link libavhot.so.  Returns the library path."""
     cc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
-    hm = _deps_mtime()
     todo, objs = [], []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < _deps_mtime(src):
             todo.append((src, obj))
 
     def compile_one(so):

@@ -75,7 +75,7 @@ __host__ __device__ inline int even_up(int v) { return (v + 1) & ~1; }
 
 // doubles of dynamic LDS for G start states per workgroup of NW waves
 __host__ __device__ inline size_t plan_lds_doubles(int G, int n, int C, int NW = 4) {
-    return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + even_up(G * C) + (size_t)NW * n * 6;
+    return (size_t)G * 3 * n * 2 + even_up(G * 3 * 3) + (size_t)G * 8 + (size_t)3 * even_up(G * C) + (size_t)NW * n * 6;
 }
 
 // Orders this wave's LDS accesses for the compiler.  The hardware executes one wave's DS operations
@@ -88,13 +88,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // The workgroup-cooperative planner for small batches (and n > 64): G consecutive start states f0 .. f0 + G - 1 by a workgroup of
 // NW waves.  A device function, so that the fused time-step kernel (step.hip) runs the very same code after its Kalman step.
-//   phase 1  per (state, speed) pair, dealt to the waves: lanes make the per-waypoint terms in parallel (velocity blend v_i, v_i dt,
-//            the velocity and acceleration cost terms -- the 50 float64 divides of the acceleration used to sit in ONE lane's
-//            sequential loop, 8 of the kernel's 23 us at 64 states), then lane 0 adds them up left to right in the reference's
-//            order: identical bits, a chain of additions only
+//   phase 1  per (state, speed) pair, one wave each: lanes make the per-waypoint terms in parallel (velocity blend v_i, v_i dt, the
+//            velocity and acceleration cost terms -- the 50 float64 divides of the acceleration used to sit in ONE lane's
+//            sequential loop) and the wave adds up the arc length s_i = s_{i-1} + v_i dt left to right, the reference's order
+//            (:156-157), terms broadcast from registers by v_readlane: no memory access on the sequential path.  Only this
+//            chain is in front of the barrier; the two cost chains (:235-244) have no consumer before phase 3 and run behind
+//            it, in the same waves, which in exchange get fewer trajectories (in-kernel cycle stamps: the three chains back to
+//            back were 6 of the kernel's 14 us for one start state)
 //   phase 2  each wave takes whole trajectories; lane = waypoint (positions, tangent heading by atan2_fast, curvature, cost terms;
-//            AoS image assembled in a per-wave LDS tile and streamed out as 16-byte-per-lane stores)
-//   phase 3  stable rank of the C costs (== Python's stable sort, :300)
+//            AoS image assembled in a per-wave LDS tile and streamed out as 16-byte-per-lane stores); per-trajectory sums by DPP
+//   phase 3  costs assembled in the reference's order of accumulation, stable rank of the C costs (== Python's stable sort, :300)
 template <int G, int NW>
 __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_states, const double* __restrict__ state,
                                            const double* __restrict__ ref, int n_ref, const double* __restrict__ obs, int n_obs,
@@ -103,71 +106,139 @@ __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_st
     double* vs = sm;                                   // [G][3][n][2]  (v, s)
     double* base = vs + (size_t)G * 3 * n * 2;         // [G][3][3]     S_v, S_a, running(S_v then acc terms)
     double* trig = base + even_up(G * 3 * 3);          // [G][8]        x0 y0 cos sin cos(h+pi/2) sin(h+pi/2) h0
-    double* costs = trig + G * 8;                      // [G][C]
-    double* stage_all = costs + even_up(G * C);        // [NW][n*6]
+    double* costs = trig + G * 8;                      // [3][G][C]     per trajectory: reference-path, curvature, obstacle sums; then [0]: the cost
+    double* stage_all = costs + 3 * even_up(G * C);    // [NW][n*6]
+    const int CS = even_up(G * C);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double* stage = stage_all + (size_t)wid * n * 6;
+    constexpr int P = G * 3;                           // (state, speed) pairs
+    static_assert(P <= NW || NW == 4, "one wave per pair keeps the cost terms in its registers");
+
+    auto bcast = [&](double x, int i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(x), i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)__double_as_longlong(x) >> 32), i);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    auto terms = [&](double v0, double dv, int i, double& v, double& vdt, double& velt, double& acct) {
+        v = v0 + dv * p.alpha[i];                             // :153-154
+        vdt = v * p.dt;
+        const double e = v - 10.0;
+        velt = p.w_vel * (e * e);                             // :236
+        acct = 0.0;
+        if (i > 0) {                                          // (added up only where dtd[i] > 0, like the reference's test)
+            const double vp = v0 + dv * p.alpha[i - 1];
+            const double a = (v - vp) / p.dtd[i];
+            acct = p.w_acc * (a * a);                         // :244
+        }
+    };
+    // the cost chains of one pair from its terms: S_v over all waypoints, then the acceleration terms on top (:235-244)
+    auto cost_chains = [&](double velt, double acct, unsigned long long hasm, double* b) {
+        double sv = 0.0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            if (i < n) sv = sv + bcast(velt, i);
+        double run = sv, sa = 0.0;
+#pragma unroll
+        for (int i = 1; i < 64; ++i)
+            if (i < n && ((hasm >> i) & 1ull)) {
+                const double term = bcast(acct, i);
+                run = run + term, sa = sa + term;
+            }
+        if (lane == 0) b[0] = sv, b[1] = sa, b[2] = run;
+    };
 
     // ---- phase 1 ---------------------------------------------------------------------------------
-    for (int pr = wid; pr < G * 3; pr += NW) {
-        const int g = pr / 3, k = pr - g * 3, f = f0 + g;
-        if (f >= n_states) continue;
-        const double v0 = state[(size_t)f * 4 + 3];
-        const double vt = 8.0 + 2.0 * (double)k;              // [8.0, 10.0, 12.0]  (:280)
-        const double dv = vt - v0;
-        double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
-        double* tv = stage;                                   // [n] v_i dt | [n] velocity cost term | [n] acceleration cost term
-        for (int i = lane; i < n; i += 64) {
-            const double v = v0 + dv * p.alpha[i];            // :153-154
-            o[2 * i] = v;
-            tv[i] = v * p.dt;
-            const double e = v - 10.0;
-            tv[n + i] = p.w_vel * (e * e);                    // :236
-            double term = 0.0;
-            if (i > 0) {                                      // (used below only where dtd[i] > 0, like the reference's test)
-                const double vp = v0 + dv * p.alpha[i - 1];
-                const double a = (v - vp) / p.dtd[i];
-                term = p.w_acc * (a * a);                     // :244
+    const bool fast = n <= 64 && P <= NW;              // terms in registers, one pair per wave
+    double k_velt = 0.0, k_acct = 0.0;                 // this wave's pair: cost terms kept for after the barrier
+    unsigned long long k_has = 0;
+    bool k_live = false;
+    if (fast) {
+        if (wid < P) {
+            const int g = wid / 3, k = wid - g * 3, f = f0 + g;
+            if (f < n_states) {
+                const double v0 = state[(size_t)f * 4 + 3];
+                const double vt = 8.0 + 2.0 * (double)k;      // [8.0, 10.0, 12.0]  (:280)
+                const double dv = vt - v0;
+                double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
+                double v = 0.0, vdt = 0.0;
+                bool has = false;
+                if (lane < n) terms(v0, dv, lane, v, vdt, k_velt, k_acct), has = lane > 0 && p.dtd[lane] > 0.0;
+                k_has = __ballot(has), k_live = true;
+                double sacc = 0.0, my_s = 0.0;
+#pragma unroll
+                for (int i = 1; i < 64; ++i)
+                    if (i < n) {
+                        sacc = sacc + bcast(vdt, i);          // :157
+                        my_s = lane == i ? sacc : my_s;
+                    }
+                if (lane < n) o[2 * lane] = v, o[2 * lane + 1] = my_s;
             }
-            tv[2 * n + i] = term;
         }
-        wave_lds_fence();
-        if (lane == 0) {
-            double sacc = 0.0, sv = 0.0;
-            o[1] = 0.0;
-            sv = sv + tv[n];
-            for (int i = 1; i < n; ++i) {
-                sacc = sacc + tv[i];                          // :157
-                o[2 * i + 1] = sacc;
-                sv = sv + tv[n + i];
-            }
-            double run = sv, sa = 0.0;
-            for (int i = 1; i < n; ++i) {
-                if (p.dtd[i] > 0.0) {
-                    const double term = tv[2 * n + i];
-                    run = run + term, sa = sa + term;
-                }
-            }
+    } else {
+        for (int pr = wid; pr < P; pr += NW) {
+            const int g = pr / 3, k = pr - g * 3, f = f0 + g;
+            if (f >= n_states) continue;
+            const double v0 = state[(size_t)f * 4 + 3];
+            const double vt = 8.0 + 2.0 * (double)k;
+            const double dv = vt - v0;
+            double* o = vs + ((size_t)(g * 3 + k) * n) * 2;
             double* b = base + (g * 3 + k) * 3;
-            b[0] = sv, b[1] = sa, b[2] = run;
+            double* tv = stage;                               // [n] v_i dt | [n] velocity cost term | [n] acceleration cost term
+            for (int i = lane; i < n; i += 64) {
+                double v, vdt, velt, acct;
+                terms(v0, dv, i, v, vdt, velt, acct);
+                o[2 * i] = v, tv[i] = vdt, tv[n + i] = velt, tv[2 * n + i] = acct;
+            }
+            wave_lds_fence();
+            if (lane == 0) {
+                double sacc = 0.0, sv = 0.0;
+                o[1] = 0.0;
+                sv = sv + tv[n];
+                for (int i = 1; i < n; ++i) {
+                    sacc = sacc + tv[i];                      // :157
+                    o[2 * i + 1] = sacc;
+                    sv = sv + tv[n + i];
+                }
+                double run = sv, sa = 0.0;
+                for (int i = 1; i < n; ++i) {
+                    if (p.dtd[i] > 0.0) {
+                        const double term = tv[2 * n + i];
+                        run = run + term, sa = sa + term;
+                    }
+                }
+                b[0] = sv, b[1] = sa, b[2] = run;
+            }
+            wave_lds_fence();
         }
-        wave_lds_fence();
     }
-    if (tid < G) {
-        const int g = tid, f = f0 + g;
+    // heading terms: the last wave (free in phase 1 when the pairs are fewer than the waves), two lanes per state -- lane 2 g takes
+    // sin / cos of the heading, lane 2 g + 1 of heading + pi/2 (one sincos each, side by side)
+    if (wid == NW - 1 && lane < 2 * G) {
+        const int g = lane >> 1, f = f0 + g;
         if (f < n_states) {
             const double h0 = state[(size_t)f * 4 + 2];
-            const double hp = h0 + 1.5707963267948966;           // heading0 + np.pi/2  (:179)
             double* tg = trig + g * 8;
-            tg[0] = state[(size_t)f * 4 + 0], tg[1] = state[(size_t)f * 4 + 1];
-            tg[2] = cos(h0), tg[3] = sin(h0), tg[4] = cos(hp), tg[5] = sin(hp), tg[6] = h0;
+            double sn, cs;
+            if (lane & 1) {
+                sincos(h0 + 1.5707963267948966, &sn, &cs);       // heading0 + np.pi/2  (:179)
+                tg[4] = cs, tg[5] = sn;
+            } else {
+                sincos(h0, &sn, &cs);
+                tg[0] = state[(size_t)f * 4 + 0], tg[1] = state[(size_t)f * 4 + 1];
+                tg[2] = cs, tg[3] = sn, tg[6] = h0;
+            }
         }
     }
     __syncthreads();
+    if (k_live) cost_chains(k_velt, k_acct, k_has, base + wid * 3);        // consumed in phase 3
 
     // ---- phase 2 ---------------------------------------------------------------------------------
-    for (int j = wid; j < G * C; j += NW) {
+    // the per-waypoint constants of this lane's first waypoint, loaded once (not once per trajectory behind the LDS fences)
+    const double q_l = lane < n ? p.q[lane] : 0.0, q_l1 = lane + 1 < n ? p.q[lane + 1] : 0.0, t_l = lane < n ? p.t[lane] : 0.0;
+    const bool extra = n_ref > 0 || n_obs > 0;
+    // trajectories are dealt round-robin starting BEHIND the waves that still have cost chains to add up
+    for (int j = fast ? (wid - P % NW + NW) % NW : wid; j < G * C; j += NW) {
         const int g = j / C, c = j - g * C, f = f0 + g;
         if (f >= n_states) continue;
         const int li = c / 3, k = c - li * 3;
@@ -178,18 +249,19 @@ __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_st
 
         for (int i = lane; i < n; i += 64) {
             const double v = o[2 * i], s = o[2 * i + 1];
-            const double d = df * p.q[i];
+            const bool first = i == lane;
+            const double d = df * (first ? q_l : p.q[i]);
             double x = x0 + s * cs, y = y0 + s * sn;            // :175-176
             x = x + d * c2, y = y + d * s2;                     // :179-180
             double hd = 0.0;
             if (i < n - 1) {
-                const double s1 = o[2 * i + 3], d1 = df * p.q[i + 1];
+                const double s1 = o[2 * i + 3], d1 = df * (first ? q_l1 : p.q[i + 1]);
                 double x1 = x0 + s1 * cs, y1 = y0 + s1 * sn;
                 x1 = x1 + d1 * c2, y1 = y1 + d1 * s2;
                 hd = atan2_fast(y1 - y, x1 - x, p.atq);         // :188
             }
             double* w = stage + (size_t)i * 6;
-            w[0] = x, w[1] = y, w[2] = hd, w[3] = v, w[4] = p.t[i], w[5] = 0.0;
+            w[0] = x, w[1] = y, w[2] = hd, w[3] = v, w[4] = first ? t_l : p.t[i], w[5] = 0.0;
         }
         wave_lds_fence();
         double lat_sum = 0.0, curv_sum = 0.0, obs_sum = 0.0;
@@ -222,13 +294,9 @@ __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_st
         }
         wave_lds_fence();
         if (lane == 0) stage[(size_t)(n - 1) * 6 + 2] = n > 1 ? stage[(size_t)(n - 2) * 6 + 2] : h0;   // :190
-        lat_sum = wave_sum(lat_sum), curv_sum = wave_sum(curv_sum), obs_sum = wave_sum(obs_sum);
-        if (lane == 0) {
-            const double* b = base + (g * 3 + k) * 3;
-            // reference accumulates [ref-path] -> velocity -> acceleration -> curvature -> obstacles
-            const double va = n_ref > 0 ? (lat_sum + b[0]) + b[1] : b[2];
-            costs[g * C + c] = (va + curv_sum) + obs_sum;
-        }
+        curv_sum = wave_sum_dpp(curv_sum);
+        if (extra) lat_sum = wave_sum_dpp(lat_sum), obs_sum = wave_sum_dpp(obs_sum);
+        if (lane == 0) costs[g * C + c] = lat_sum, costs[CS + g * C + c] = curv_sum, costs[2 * CS + g * C + c] = obs_sum;
         wave_lds_fence();
         if (wp) {
             const double2* src = reinterpret_cast<const double2*>(stage);
@@ -239,7 +307,16 @@ __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_st
     }
     __syncthreads();
 
-    // ---- phase 3: stable ascending rank (:300) -----------------------------------------------------
+    // ---- phase 3: costs, stable ascending rank (:300) -------------------------------------------------------------------------
+    for (int idx = tid; idx < G * C; idx += NW * 64) {
+        const int g = idx / C, c = idx - g * C, k = c % 3;
+        const double* b = base + (g * 3 + k) * 3;
+        // reference accumulates [ref-path] -> velocity -> acceleration -> curvature -> obstacles
+        const double va = n_ref > 0 ? (costs[idx] + b[0]) + b[1] : b[2];
+        const double total = (va + costs[CS + idx]) + costs[2 * CS + idx];
+        costs[idx] = total;
+    }
+    __syncthreads();
     for (int idx = tid; idx < G * C; idx += NW * 64) {
         const int g = idx / C, c = idx - g * C, f = f0 + g;
         if (f >= n_states) continue;
