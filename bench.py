@@ -13,8 +13,12 @@ At N = 1 the same JSON line carries, under "also", the other single-GPU configur
   config3      YOLO-mode detector (MFMA convs) + Canny/Hough lane detector on device-generated 1280x720 frames
   config2      1 stream, simulated detection (latency-bound: one dependent chain)
   config2_w1   config 2 with window 1
-each with the per-stage kernel list (isolated HIP-event times on the launch stream, share of their sum, what bounds
-the stage, achieved vs peak) and the roofline of the stage that dominates that configuration's step.
+each as a compact summary (value, ms_per_step, dtype, roofline of the stage that dominates that configuration's step, CPU
+baseline); the printed line stays under 8 KB.  The full records -- every configuration's per-stage kernel list (isolated
+HIP-event times on the launch stream, share of their sum, what bounds the stage, achieved vs peak) -- go to the side file
+named in "detail_file" (default gpurun_out/bench_detail.json; a builder-run copy is committed as profiles/rNN_bench_kernels.json).
+`traffic` values are PMC counter results read from profiles/*_pmc.json; each of those files carries the hash of the kernel
+source it was measured on, and a value whose source has changed since is printed as null ("traffic_stale": true).
 `cpu_baseline` legs are timed BEFORE the GPU is initialised (the nproc leg starts child processes).
 """
 import argparse
@@ -62,6 +66,8 @@ def parse():
     ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step")
     ap.add_argument("--taggers", action="store_true",
                     help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="side file for the full per-configuration records (kernel lists)")
     return ap.parse_args()
 
 
@@ -175,24 +181,34 @@ def time_stage(L, nat, stream, fn, reps, sync):
     return ms
 
 
-def pmc_traffic(name, key, scale):
+def _pmc_load(name):
+    """A counter profile under profiles/, or None when it is missing or no longer describes the kernel in the tree: every
+    profile carries the sha256 (first 16 hex digits) of the kernel source file it was measured on (tools/profiles_from_db.py)."""
+    import hashlib
     p = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(p):
-        try:
-            return int(json.load(open(p))[key] * scale)
-        except Exception:
+    try:
+        j = json.load(open(p))
+        src = os.path.join(ROOT, PKG, j["kernel_source"])
+        if hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] != j["kernel_source_sha256_16"]:
             return None
-    return None
+        return j
+    except Exception:
+        return None
+
+
+def pmc_traffic(name, key, scale):
+    j = _pmc_load(name)
+    return int(j[key] * scale) if j is not None and key in j else None
 
 
 def pmc_value(name, key):
-    p = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(key)
-        except Exception:
-            return None
-    return None
+    j = _pmc_load(name)
+    return j.get(key) if j is not None else None
+
+
+def pmc_stamp(name):
+    j = _pmc_load(name)
+    return {"file": "profiles/" + name, "commit": j.get("measured_at_commit")} if j is not None else {"file": "profiles/" + name, "stale": True}
 
 
 def finish_kernel_list(ks):
@@ -237,13 +253,19 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     loop.load_measurements(z)
     xchg = None
     if world > 1 and not a.no_allgather:
-        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame"))
+        # window 1: every step IS a frame, so the per-frame gather (config 5's wording) is the default there -- and with the
+        # one-launch step the wire tables come out of the step kernel itself (no pack launch)
+        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame" or W == 1))
     h, s = loop.ctx.handle, loop._s
     cross = xchg is not None or a.taggers     # somebody on the main stream reads the tracker's tables every step
 
     def one_step():
+        if xchg is not None:
+            xchg.begin_step()                 # (one-launch step: this step writes its wire tables into the exchange's send buffer)
         if graph:
-            loop.step(graph=True)             # fork{detect; track} || {kf; plan}; join -- inside the graph
+            loop.step(graph=True)             # fork{detect; track} || {kf; plan}; join -- inside the graph (window 1: one kernel)
+        elif loop.fused_step:
+            loop.enqueue_step()               # window 1: one launch
         else:
             # side stream: detect -> track; main: kf -> plan.  When the main stream reads the tracker's tables every
             # step (exchange / interaction tagger) the side stream must first wait for the previous step's readers
@@ -265,7 +287,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
             xchg.exchange()
 
     def drain():
-        if not graph:
+        if not graph and not loop.fused_step:
             nat.check(L.av_join(h, s))       # main stream waits for the side stream's tail
         loop.synchronize()
         if xchg is not None:
@@ -322,14 +344,32 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                "bytes_per_launch": SIMDET_BYTES * F, "achieved": hbm(SIMDET_BYTES * F, t_det), "peak": HBM_PEAK_GBS,
                "unit": "GB/s", "frac": round(hbm(SIMDET_BYTES * F, t_det) / HBM_PEAK_GBS, 5)})
     side, main = t_det + t_trk, t_kf + t_pl
+    stage_kernels = None
+    if loop.fused_step:
+        # the step IS one kernel: it is the roofline entry; the four stage kernels it replaces are kept beside it for comparison
+        t_fused = time_stage(L, nat, s, loop.enqueue_step_fused, stage_reps, sync)
+        stage_kernels = finish_kernel_list(ks)
+        ks = [{"kernel": "hot_step_kernel", "stage": "detect + track || Kalman + plan (one launch, role-split workgroups)", "branch": "main",
+               "avg_ms": t_fused, "bound": "latency",
+               "why": "one frame per stream and launch: per stream a detector row + tracker frame in one workgroup, Kalman step + 21 "
+                      "trajectories in another; %d of %d CUs, microseconds of dependent work each" % (min(2 * S, N_CUS), N_CUS),
+               "cus_occupied": min(2 * S, N_CUS), "bytes_per_launch": (TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb,
+               "achieved": hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused) / HBM_PEAK_GBS, 5), "traffic": None}]
     dom = max(ks, key=lambda k: k["avg_ms"])
     roof = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch") if k in dom}
     roof["avg_launch_ms"] = round(dom["avg_ms"], 5)
     roof["traffic"] = dom.get("traffic")
+    if dom.get("traffic") is None and dom["kernel"] in ("tracker_kernel", "planner_wave_kernel"):
+        roof["traffic_stale"] = True         # the counter profile was measured on another version of the kernel's source
     if dom["bound"] == "latency":
         roof["cus_occupied"] = dom.get("cus_occupied")
         roof["note"] = ("dominant kernel is a per-stream sequential chain on %d of %d CUs; its HBM fraction is reported for "
-                        "completeness, the HBM-bound kernel of this step is the planner (see kernels)" % (dom.get("cus_occupied", 0), N_CUS))
+                        "completeness%s" % (dom.get("cus_occupied", 0), N_CUS,
+                                            "" if loop.fused_step else ", the HBM-bound kernel of this step is the planner (see kernels)"))
+    planner_k = next((k for k in (stage_kernels or ks) if k["kernel"] == "planner_wave_kernel"), None)
+    if planner_k is not None and not loop.fused_step:
+        roof["hbm_bound_kernel_beside_it"] = {k: planner_k[k] for k in ("kernel", "avg_ms", "achieved", "frac", "traffic", "bytes_per_launch")}
     step_bytes = (TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb
     out = {"metric": METRIC, "value": round(F * steps * world / el, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 5), "higher_is_better": True,
@@ -337,7 +377,8 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
            "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window per step, 1280x720, simulated detection + IoU "
                                   "tracker + 6-state KF + 21-candidate planner%s" % (name, S, W, ", one hipGraph replay per step" if graph else ""),
                       "streams_per_gpu": S, "window": W, "graph": bool(graph), "taggers": bool(a.taggers),
-                      "allgather_track_tables": (a.gather if xchg is not None else False),
+                      "allgather_track_tables": (("per-frame" if xchg.per_frame else "window-end") if xchg is not None else False),
+                      "fused_step": bool(loop.fused_step),
                       "parallelism": "stream-sharded x%d" % world},
            "roofline": roof, "kernels": finish_kernel_list(ks),
            "step": {"critical_branch": "side (detect+track)" if side > main else "main (kf+plan)",
@@ -347,6 +388,9 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
     if xchg is not None:
         out["config"]["allgather_bytes_per_rank_per_step"] = xchg.bytes_per_step
+    if stage_kernels is not None:
+        out["stage_kernels_replaced"] = stage_kernels
+    out["traffic_profiles"] = [pmc_stamp("tracker_pmc.json"), pmc_stamp("planner_pmc.json")]
     if W == 1:
         out["us_per_time_step"] = round(el / steps * 1e6, 3)
     del loop, xchg
@@ -411,9 +455,10 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     tf = fl / (t_yolo * 1e-3) / 1e12
     pix_bytes = loop.lane_pixel_bytes_per_px * px
     ks = [
-        {"kernel": "yolo forward: preprocess + stem + fused C2f (layer 2) + 58 conv launches (conv3x3_ws_kernel / "
-                   "conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel; decode in the head's last convolutions) + sppf + upsample + "
-                   "sort + NMS", "stage": "detect", "branch": "main", "avg_ms": t_yolo, "bound": "mfma",
+        {"kernel": "yolo forward: front_fused_kernel (letterbox + stem + layer 1) + c2f16_fused_kernel (layer 2) + c2f32_head/tail "
+                   "kernels (layers 4, 15) + 47 conv launches (conv3x3_ws_kernel / conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel; "
+                   "decode in the head's last convolutions) + sppf + upsample + radix sort + NMS", "stage": "detect", "branch": "main",
+         "avg_ms": t_yolo, "bound": "mfma",
          "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
         {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",
@@ -451,6 +496,7 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
                           "frac": round(lane_total / (lane_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "SURVEY 8d: 7*W*H algorithmic bytes per frame over pixel stages + Hough + fit"},
            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
+    out["traffic_profiles"] = [pmc_stamp("lane_pmc.json"), pmc_stamp("yolo_mfma_pmc.json")]
     del loop
     torch.cuda.empty_cache()
     return out
@@ -488,6 +534,14 @@ def run_per_frame_classes(local, frames=220, warm=20):
             for k, v in zip(names, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 T[k].append(v * 1e3)
     T = {k: np.array(v) for k, v in T.items()}
+    # the YOLO-mode detector through the same class surface (random-init YOLOv8n topology): one pinned upload, one mapped result read
+    ydet = ObjectDetector(mode="yolo", model_path="random:0", device=local)
+    ty = []
+    for i in range(60):
+        t0 = time.perf_counter()
+        ydet.detect(imgs[i % 8])
+        if i >= 10:
+            ty.append((time.perf_counter() - t0) * 1e3)
     no_lane = T["detect"] + T["track"] + T["kf"] + T["plan"]
     tot = no_lane + T["lane"]
     return {"frames": frames, "what": "ObjectDetector(simulated) -> LaneDetector -> MultiObjectTracker -> VehicleStateEstimator -> "
@@ -496,7 +550,10 @@ def run_per_frame_classes(local, frames=220, warm=20):
             "ms_per_frame_without_lanes_median": round(float(np.median(no_lane)), 4),
             "ms_per_frame_without_lanes_mean": round(float(no_lane.mean()), 4),
             "frames_per_s_median": round(1e3 / float(np.median(tot)), 1),
-            "stage_ms_median": {k: round(float(np.median(v)), 4) for k, v in T.items()}}
+            "stage_ms_median": {k: round(float(np.median(v)), 4) for k, v in T.items()},
+            "yolo_mode_detect_ms_median": round(float(np.median(ty)), 4),
+            "yolo_mode_what": "ObjectDetector(mode='yolo', model_path='random:0').detect(frame): upload + 1-image forward + sort + NMS + "
+                              "host-visible Detection list"}
 
 
 def run_bev_panels(local, S=64, W=16, reps=10):
@@ -517,6 +574,46 @@ def run_bev_panels(local, S=64, W=16, reps=10):
             "bytes_per_launch": 12 * px, "achieved": round(12 * px / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
             "note": "12 B/px: the road image read and written by the copy, read and written again by the rasteriser; the per-tile "
                     "walk over the primitive list, not memory, sets the time"}
+
+
+def _short(txt, n=140):
+    return txt if len(txt) <= n else txt[:n - 3] + "..."
+
+
+def compact_summary(v):
+    """One `also` entry as the driver keeps it: value, time per step, dtype, the dominant stage's roofline, the CPU baseline."""
+    if "value" not in v:                                  # per_frame_classes / bev_panels: already small
+        return {k: (_short(x, 160) if isinstance(x, str) else x) for k, x in v.items() if k not in ("kernels", "note")}
+    out = {"value": v["value"], "unit": v.get("unit"), "ms_per_step": v.get("ms_per_step"), "dtype": v.get("dtype"),
+           "steps": v.get("steps"), "workload": _short(v.get("config", {}).get("workload", ""), 150)}
+    if "us_per_time_step" in v:
+        out["us_per_time_step"] = v["us_per_time_step"]
+    r = v.get("roofline", {})
+    out["roofline"] = {k: (_short(r[k], 90) if isinstance(r[k], str) else r[k])
+                       for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_ms",
+                                 "cus_occupied", "mfma_busy_pmc_percent") if k in r}
+    if "hbm_bound_kernel_beside_it" in r:
+        out["roofline"]["hbm_bound_kernel_beside_it"] = r["hbm_bound_kernel_beside_it"]
+    if "lane_chain" in v:
+        out["lane_chain"] = {k: v["lane_chain"][k] for k in ("avg_ms", "achieved", "frac", "unit")}
+        out["stage_ms"] = {k["stage"]: k["avg_ms"] for k in v.get("kernels", [])}
+    c = v.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind", "gpu_over_cpu", "gpu_over_cpu_nproc") if k in c}
+        if "nproc" in c:
+            out["cpu_baseline"]["nproc"] = {k: c["nproc"][k] for k in ("value", "cores")}
+    return out
+
+
+def compact_line(head):
+    """The printed line: the headline in full except its long texts, `also` as compact summaries."""
+    line = {k: v for k, v in head.items() if k not in ("also", "kernels", "stage_kernels_replaced")}
+    line["kernels"] = [{k: (_short(x, 100) if isinstance(x, str) else x) for k, x in kk.items() if k != "why"} for kk in head.get("kernels", [])]
+    if "cpu_baseline" in line and "sample" in line["cpu_baseline"]:
+        line["cpu_baseline"] = dict(line["cpu_baseline"], sample=_short(line["cpu_baseline"]["sample"], 200))
+    if "also" in head:
+        line["also"] = {k: compact_summary(v) for k, v in head["also"].items()}
+    return line
 
 
 def main():
@@ -582,7 +679,16 @@ def main():
         head["also"] = also
 
     if rank == 0:
-        print(json.dumps(head), flush=True)
+        # full records (kernel lists) -> side file; the printed line carries compact per-configuration summaries (< 8 KB)
+        detail = json.loads(json.dumps(head))
+        try:
+            os.makedirs(os.path.dirname(a.detail_out), exist_ok=True)
+            with open(a.detail_out, "w") as f:
+                json.dump(detail, f, indent=1)
+            head["detail_file"] = os.path.relpath(a.detail_out, ROOT)
+        except OSError:
+            head["detail_file"] = None
+        print(json.dumps(compact_line(head)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

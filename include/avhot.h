@@ -448,7 +448,8 @@ int av_synth_frames(av_ctx* ctx, av_stream_t stream, int n_streams, int h, int w
  *   z [S][4]; kf_state [S][AV_KF_STATE_DOUBLES]; vstate [S][AV_VSTATE_DOUBLES]; plan_state [S][4];
  *   waypoints [S][C][n][6] or NULL; cost, order [S][C];
  *   wire: NULL, or [S][av_wire_table_bytes(tcap)] -- every stream's table in the all-gather's wire format (av_pack_tracks with
- *   n_sel = 1), written by the same launch (needs snap); stream0 / frame0 go into the headers.
+ *   n_sel = 1), written by the same launch (needs snap); header.stream = stream0 + s, header.frame = frame0 + frame_count[s]
+ *   after the step (the stream's own detector frame count, read on the device: a captured graph stamps every replay correctly).
  * Built for tcap 64, dcap 7..8, iou_threshold > 0 (AV_EINVAL otherwise: use the stage calls). */
 int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg, int n_streams, int h,
                 int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,

@@ -1,6 +1,8 @@
 // Context, error reporting, fork/join, hipGraph capture and event helpers of libavhot.so.
 #include "common.h"
 
+#include <chrono>
+
 #include <cstring>
 
 static thread_local char g_err[512] = "no error";
@@ -187,17 +189,33 @@ int av_stream_sync(av_stream_t stream) {
 }
 
 // Waits for the stream by polling an event instead of sleeping on the completion interrupt: a per-frame call waits for
-// ~10 us of work, and the interrupt path's wake-up latency is of that order.
+// ~10 us of work, and the interrupt path's wake-up latency is of that order.  The event belongs to the device that is
+// current when it is recorded (one per device and thread, created on first use); the poll is bounded -- after 2 ms without
+// completion the wait falls back to hipStreamSynchronize, whose error (a faulted or hung kernel) is returned instead of
+// spinning a core forever.
 int av_stream_sync_spin(av_stream_t stream) {
-    static thread_local hipEvent_t ev = nullptr;
+    constexpr int MAX_DEV = 16;
+    static thread_local hipEvent_t evs[MAX_DEV] = {};
+    int dev = 0;
+    AV_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) {
+        AV_HIP(hipStreamSynchronize(as_stream(stream)));
+        return AV_OK;
+    }
+    hipEvent_t& ev = evs[dev];
     if (!ev) AV_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     AV_HIP(hipEventRecord(ev, as_stream(stream)));
-    for (;;) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return AV_OK;
         if (e != hipErrorNotReady) {
             av_set_error("av_stream_sync_spin: hipEventQuery -> %s", hipGetErrorString(e));
             return AV_EHIP;
+        }
+        if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            AV_HIP(hipStreamSynchronize(as_stream(stream)));
+            return AV_OK;
         }
         __builtin_ia32_pause();
     }

@@ -55,7 +55,9 @@ __global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
                 uint8_t* dst = a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES);
                 if (r == 0) {
                     av_wire_hdr hd;
-                    hd.n_rows = n < a.tcap ? n : a.tcap, hd.stream = a.stream0 + s, hd.frame = a.frame0, hd.reserved = 0;
+                    // frame = frame0 + the stream's detector frame count after this step: read from memory, so that a captured graph
+                    // (fixed kernel arguments) stamps every replay with its own index
+                    hd.n_rows = n < a.tcap ? n : a.tcap, hd.stream = a.stream0 + s, hd.frame = a.frame0 + a.frame_count[s], hd.reserved = 0;
                     *reinterpret_cast<av_wire_hdr*>(dst) = hd;
                 }
                 av_wire_row o;

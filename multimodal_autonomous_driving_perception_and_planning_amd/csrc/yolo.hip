@@ -43,6 +43,10 @@ struct ConvArgs {
     half_t* out;        float* out32; int out_cs, out_coff, cout, Ho, Wo;
     const half_t* res;  int res_cs, res_coff;                 // optional residual (added after the activation)
     int act, npix;                                            // npix = B*Ho*Wo
+    // virtual Upsample + Concat in front of a 1x1 convolution (the neck's C2f cv1 at P4 / P3): input channels [0, k1) are `in` read at
+    // HALF resolution (pixel (y >> 1, x >> 1): nearest-neighbour x2), channels [k1, cin) are `in2` at full resolution.  in2 = NULL:
+    // one ordinary input.  The upsampled copy (63 / 126 MB per 64 frames) is then neither written nor read.
+    const half_t* in2;  int in2_cs, in2_coff, k1;
 };
 
 // SiLU with v_rcp_f32 (1 ulp) instead of an IEEE divide: the result is rounded to half anyway, and the epilogue of
@@ -193,16 +197,26 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     constexpr int NP = (PH * PW * 4 + 255) / 256, NW = (16 * MT * taps * 4 + 255) / 256;
     const int part8 = (tid & 3) * 8;           // every piece of this thread is the same 8-channel part of a chunk
     int p_g[NP], p_l[NP], w_g[NW], w_l[NW];
+    int p_g2[KS == 1 ? NP : 1];                // second source of a virtual Upsample + Concat (1x1 only): offset into a.in2, minus k1
+    const bool dual = KS == 1 && a.in2 != nullptr;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int i = tid + k * 256;
         p_g[k] = -1, p_l[k] = -1;
+        if (KS == 1) p_g2[k] = -1;
         if (i < PH * PW * 4) {
             const int pix = i >> 2, part = i & 3;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = iy_org + py, ix = ix_org + px;
             p_l[k] = pix * PIXB + part * 16;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) p_g[k] = ((n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                if (dual) {
+                    p_g[k] = ((n * (a.H >> 1) + (iy >> 1)) * (a.W >> 1) + (ix >> 1)) * a.in_cs + a.in_coff + part * 8;
+                    if (KS == 1) p_g2[k] = ((n * a.H + iy) * a.W + ix) * a.in2_cs + a.in2_coff + part * 8 - a.k1;
+                } else {
+                    p_g[k] = ((n * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * 8;
+                }
+            }
         }
     }
 #pragma unroll
@@ -218,9 +232,12 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(ConvArgs a, int tiles_x, 
     uint4 pv[NP], wv[NW];
     auto gload = [&](int c0) {
         const bool inch = c0 + part8 < a.cin;  // cin need not be a multiple of the chunk: the tail is zero-filled
+        const bool second = KS == 1 && dual && c0 >= a.k1;         // (k1 is a multiple of the chunk: a chunk comes from one source)
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-            pv[k] = (p_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(a.in + (size_t)p_g[k] + c0) : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < NP; ++k) {
+            const half_t* src = second ? a.in2 + (size_t)p_g2[KS == 1 ? k : 0] : a.in + (size_t)p_g[k];
+            pv[k] = (p_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(src + c0) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int k = 0; k < NW; ++k)
             wv[k] = (w_g[k] >= 0 && inch) ? *reinterpret_cast<const uint4*>(a.wgt + (size_t)w_g[k] + c0) : make_uint4(0, 0, 0, 0);
@@ -1764,7 +1781,8 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
-    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; };   // lane 1: internal side stream;
+    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; int vcat = -1; };   // lane 1: internal side stream;
+    // vcat >= 0 (an upsample op): op index of the 1x1 convolution that can read this upsample's source directly (virtual Upsample + Concat);
     // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch; 2 / 3: 32-channel blocks (c2f32_*); dec 1 / 2: the head's last box /
     // class convolution of level dec_level (its epilogue can do the decode)
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
@@ -1848,6 +1866,7 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     a.res = nullptr, a.res_cs = 0, a.res_coff = 0;
     if (res) a.res = y.bufs[res->buf].p, a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
     a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
+    a.in2 = nullptr, a.in2_cs = 0, a.in2_coff = 0, a.k1 = 0;
     op.mt = (cout % 64 == 0) ? 4 : ((cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1));
     y.ops.push_back(op);
     return true;
@@ -2164,8 +2183,10 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     }
     CV(Slice{spp, 0, 512}, Slice{cat20, 128, 256}, 1, 1, true, nullptr, 0, nullptr);              // 9 SPPF cv2 -> cat20[128:384]
     add_simple(y, 2, Slice{cat20, 128, 256}, Slice{cat11, 0, 256}, H / 32, W / 32, 256);           // 10 upsample -> cat11[0:256]
+    y.ops.back().vcat = (int)y.ops.size();                                                          // (its only reader: layer 12's cv1, the next op)
     ok = ok && add_c2f(y, Slice{cat11, 0, 384}, Slice{cat17, 64, 128}, 1, false);                  // 12 -> cat17[64:192]
     add_simple(y, 2, Slice{cat17, 64, 128}, Slice{cat14, 0, 128}, H / 16, W / 16, 128);            // 13 upsample -> cat14[0:128]
+    y.ops.back().vcat = (int)y.ops.size();                                                          // (layer 15's cv1)
     ok = ok && add_c2f(y, Slice{cat14, 0, 192}, Slice{p3, 0, 64}, 1, false);                       // 15
     CV(Slice{p3, 0, 64}, Slice{cat17, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                   // 16 -> cat17[0:64]
     ok = ok && add_c2f(y, Slice{cat17, 0, 192}, Slice{p4, 0, 128}, 1, false);                      // 18
@@ -2348,6 +2369,47 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
             AV_LAUNCH_CHECK();
             oi += 3;
             continue;
+        }
+        // virtual Upsample + Concat: the upsample launch is skipped and its only reader, a 1x1 convolution on conv_lds_kernel, fetches
+        // the first k1 input channels from the half-resolution source itself (same values: bit-identical output)
+        if (op.kind == 2 && op.vcat == (int)oi + 1 && !force_direct && !getenv("AVHOT_YOLO_NO_FUSE")) {
+            const Yolo::Op& cv = y.ops[oi + 1];
+            const ConvArgs& c = cv.ca;
+            const Buf &bi = y.bufs[op.in.buf], &bo = y.bufs[op.out.buf];
+            const bool lds1x1 = cv.kind == 0 && c.ksz == 1 && c.stride == 1 && c.cin % LT_CK == 0 && op.C % LT_CK == 0 && c.in == bo.p &&
+                                c.in_coff == op.out.coff && c.in_cs == bo.C && c.H == 2 * op.H && c.W == 2 * op.W && cv.mt == 4 && c.cout % 64 == 0 &&
+                                c.cin > op.C && !c.res;
+            if (lds1x1) {
+                ConvArgs v = c;
+                v.in = bi.p, v.in_cs = bi.C, v.in_coff = op.in.coff;                       // channels [0, k1): the upsample's source, half resolution
+                v.in2 = c.in, v.in2_cs = c.in_cs, v.in2_coff = c.in_coff + op.C, v.k1 = op.C;   // channels [k1, cin): the concat buffer's own part
+                const int tiles_x = (v.Wo + LT_W - 1) / LT_W, tiles_y = (v.Ho + LT_H - 1) / LT_H;
+                const size_t lds = (((size_t)LT_H * LT_W * LT_PIXB + 15) & ~size_t(15)) + (size_t)64 * (LT_CK * 2 + 32);
+                hipLaunchKernelGGL((conv_lds_kernel<4, 1>), dim3(tiles_x * tiles_y * B, v.cout / 64), dim3(256), lds, st_main, v, tiles_x, tiles_y);
+                AV_LAUNCH_CHECK();
+                oi += 1;                                                                    // the cv1 op is done too
+                if (cv.fuse != 3) continue;
+                // layer 15's block continues with the fused pair + cv2: same code as below, cv1 already launched
+                {
+                    const ConvArgs& c1 = cv.ca;
+                    const ConvArgs& c2 = y.ops[oi + 3].ca;
+                    const bool shapes = c2.kpad == 96 && y.ops[oi + 1].ca.kpad == 288 && c2.in == c1.out && c2.in_coff == c1.out_coff && c2.in_cs == c1.out_cs &&
+                                        !getenv("AVHOT_CONV_NO_WS");
+                    if (!shapes) continue;                                                  // (the loop goes on with the unfused bottlenecks)
+                    C2f32Args fa{};
+                    fa.H = c1.H, fa.W = c1.W, fa.tiles_x = (c1.W + 15) / 16, fa.tiles_y = (c1.H + 15) / 16, fa.n_tiles = fa.tiles_x * fa.tiles_y * B;
+                    fa.cat = c1.out, fa.cat_cs = c1.out_cs, fa.cat_coff = c1.out_coff;
+                    const ConvArgs &b1 = y.ops[oi + 1].ca, &b2 = y.ops[oi + 2].ca;
+                    fa.in = c1.out, fa.in_cs = c1.out_cs, fa.in_coff = c1.out_coff + 32;
+                    fa.w_b1 = b1.wgt, fa.w_b2 = b2.wgt, fa.bs_b1 = b1.bias, fa.bs_b2 = b2.bias, fa.kb = b1.kpad;
+                    fa.w_cv2 = c2.wgt, fa.bs_cv2 = c2.bias, fa.kc = c2.kpad;
+                    fa.out = c2.out, fa.out_cs = c2.out_cs, fa.out_coff = c2.out_coff;
+                    hipLaunchKernelGGL((c2f32_tail_kernel<64, false>), dim3((unsigned)std::min(fa.n_tiles, 256)), dim3(F32_NTH), f32t_lds(64), st_main, fa);
+                    AV_LAUNCH_CHECK();
+                    oi += 3;
+                    continue;
+                }
+            }
         }
         if ((op.fuse == 2 || op.fuse == 3) && !force_direct && !getenv("AVHOT_YOLO_NO_FUSE") && !getenv("AVHOT_CONV_NO_WS")) {
             const ConvArgs& c1 = op.ca;

@@ -15,6 +15,8 @@ Two modes (bytes per rank per step at S = 64 streams, tcap = 64, 2064 B per tabl
   window-end  one table per stream per step: the table after the window's last frame        132 KB
   per-frame   every frame's table of the window (BASELINE config 5's wording); with W = 256  33.8 MB,
               with W = 1 (one step per time-step) the two modes coincide                     132 KB
+With W = 1 and the one-launch step (av_hot_step) the step kernel writes the wire tables itself, straight into the send buffer
+(TrackTableExchange.begin_step() before the step, exchange() after it): per-frame tables, no pack launch.
 """
 import numpy as np
 import torch
@@ -133,6 +135,18 @@ class TrackTableExchange:
             self.ready = [torch.cuda.Event() for _ in range(2)]
         self.done = [None, None]
         self.k = 0                      # steps exchanged so far; step k uses buffer k & 1
+        # window 1 with the one-launch step (HotLoop.fused_step): the step kernel itself writes the wire tables, straight into
+        # the send buffer handed to it by begin_step() -- no pack launch between the step and the gather
+        self.prepacked = bool(getattr(loop, "fused_step", False)) and loop.W == 1
+
+    def begin_step(self):
+        """Call BEFORE enqueuing step k when `prepacked`: hands send buffer k & 1 to the loop (after the gather that last read it)."""
+        if not self.prepacked:
+            return
+        b = self.k & 1
+        if self.gpu and self.done[b] is not None:
+            self.loop.stream.wait_event(self.done[b])
+        self.loop.set_wire(self.send[b].view(self.loop.S, -1), stream0=self.rank * self.loop.S, frame0=0)
 
     def exchange(self):
         """Enqueue pack + all-gather of the step just enqueued on loop.stream; returns the receive buffer
@@ -141,15 +155,17 @@ class TrackTableExchange:
         loop = self.loop
         frame0 = self.k * loop.W
         if not self.gpu:
-            self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0))
+            if not self.prepacked:
+                self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0))
             dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             self.k += 1
             return self.recv[b]
-        if self.done[b] is not None:           # buffer b is still being sent from two steps ago
-            loop.stream.wait_event(self.done[b])
-        nat.check(nat.lib().av_pack_tracks(loop.ctx.handle, nat.stream_handle(loop.stream), loop.S, loop.W, loop.tcap,
-                                           self.frame_lo, self.n_sel, self.rank * loop.S, frame0, nat.ptr(loop.snap),
-                                           nat.ptr(loop.snap_n), nat.ptr(self.send[b])))
+        if not self.prepacked:
+            if self.done[b] is not None:           # buffer b is still being sent from two steps ago
+                loop.stream.wait_event(self.done[b])
+            nat.check(nat.lib().av_pack_tracks(loop.ctx.handle, nat.stream_handle(loop.stream), loop.S, loop.W, loop.tcap,
+                                               self.frame_lo, self.n_sel, self.rank * loop.S, frame0, nat.ptr(loop.snap),
+                                               nat.ptr(loop.snap_n), nat.ptr(self.send[b])))
         self.ready[b].record(loop.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])

@@ -71,6 +71,7 @@ class HotLoop:
         self.order = torch.zeros(S * W, self.n_cand, dtype=i32, device=d)
         self.stream = torch.cuda.Stream(device=d)
         self.graph_id = None
+        self._graphs = {}
         can_fuse = window == 1 and tcap == 64 and 7 <= dcap <= 8 and self.tcfg.iou_threshold > 0
         if fused_step and not can_fuse:
             raise ValueError("fused_step needs window 1, tcap 64, dcap 7..8 and iou_threshold > 0")
@@ -169,7 +170,9 @@ class HotLoop:
             self._bev_n = torch.zeros(self.S, dtype=torch.int32, device=self.dev)
         st = stream or self._s
         f = self.W - 1 if frame is None else frame
-        with torch.cuda.stream(self.stream):
+        # the base image is copied on the stream the kernels run on (a caller-supplied stream must not race with it)
+        ts = self.stream if stream is None else torch.cuda.ExternalStream(stream.value if hasattr(stream, "value") else int(stream), device=self.dev)
+        with torch.cuda.stream(ts):
             self.bev.copy_(self._bev_base.unsqueeze(0).expand_as(self.bev))
         nat.check(self.L.av_bev_build(self.ctx.handle, st, C.byref(self._bev_cfg), self.S, self.W, f, self.tcap,
                                       self.tcfg.trajectory_length, nat.ptr(self.snap), nat.ptr(self.snap_n), nat.ptr(self.trk_state),
@@ -185,7 +188,8 @@ class HotLoop:
 
     def set_wire(self, wire, stream0=0, frame0=0):
         """Fused step only: `wire` (uint8 device tensor [S, av_wire_table_bytes(tcap)], or None) receives every stream's
-        track table in the all-gather's wire format from the same launch; stream0 / frame0 go into the table headers."""
+        track table in the all-gather's wire format from the same launch; header.stream = stream0 + s, header.frame =
+        frame0 + the stream's detector frame count after the step."""
         if wire is not None and not (self.fused_step and self.keep_snapshots):
             raise RuntimeError("set_wire needs the fused step and keep_snapshots=True")
         self.wire, self._wire_ids = wire, (int(stream0), int(frame0))
@@ -215,7 +219,8 @@ class HotLoop:
         nat.check(L.av_join(h, s))
 
     def capture(self):
-        """Capture enqueue_step() into a hipGraph (replayed by step(graph=True))."""
+        """Capture enqueue_step() into a hipGraph (replayed by step(graph=True)).  The fused step bakes the wire buffer's
+        address into its kernel arguments, so graphs are kept per wire buffer (the exchange alternates between two)."""
         gid = C.c_int(-1)
         nat.check(self.L.av_graph_begin(self.ctx.handle, self._s))
         try:
@@ -223,13 +228,18 @@ class HotLoop:
         finally:
             nat.check(self.L.av_graph_end(self.ctx.handle, self._s, C.byref(gid)))
         self.graph_id = gid.value
+        self._graphs[self._graph_key()] = gid.value
         return self.graph_id
+
+    def _graph_key(self):
+        return (self.wire.data_ptr(), self._wire_ids) if self.wire is not None else None
 
     def step(self, graph=False, sync=False):
         if graph:
-            if self.graph_id is None:
-                self.capture()
-            nat.check(self.L.av_graph_launch(self.ctx.handle, self.graph_id, self._s))
+            gid = self._graphs.get(self._graph_key())
+            if gid is None:
+                gid = self.capture()
+            nat.check(self.L.av_graph_launch(self.ctx.handle, gid, self._s))
         else:
             self.enqueue_step()
         if sync:

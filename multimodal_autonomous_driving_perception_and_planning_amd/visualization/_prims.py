@@ -112,17 +112,24 @@ class Raster:
         self.verts = d.zeros((1, vert_cap, 2), torch.int32)
 
     def _grow(self, np_, nv):
+        """Capacities grow in powers of two up to the kernel's limit of 65535 primitives; nothing is changed when the request
+        cannot be met (the cached Raster stays usable)."""
         d = self._dev
+        if np_ > 65535:
+            raise ValueError("too many primitives in one picture (%d > 65535)" % np_)
         if np_ > self.prim_cap:
-            while self.prim_cap < np_:
-                self.prim_cap *= 2
-            if self.prim_cap > 65535:
-                raise ValueError("too many primitives in one picture (%d)" % np_)
-            self.prims = d.zeros((1, self.prim_cap, nat.PRIM_BYTES), torch.uint8)
+            cap = self.prim_cap
+            while cap < np_:
+                cap *= 2
+            cap = min(cap, 65535)
+            self.prims = d.zeros((1, cap, nat.PRIM_BYTES), torch.uint8)
+            self.prim_cap = cap
         if nv > self.vert_cap:
-            while self.vert_cap < nv:
-                self.vert_cap *= 2
-            self.verts = d.zeros((1, self.vert_cap, 2), torch.int32)
+            cap = self.vert_cap
+            while cap < nv:
+                cap *= 2
+            self.verts = d.zeros((1, cap, 2), torch.int32)
+            self.vert_cap = cap
 
     def upload(self, img):
         self.img.copy_(torch.as_tensor(np.ascontiguousarray(img, np.uint8)).view(1, self.h, self.w, 3))

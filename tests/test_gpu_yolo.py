@@ -243,8 +243,9 @@ def test_end_to_end_detections_match_fp32_oracle(setup, tmp_path):
 def test_fused_kernels_are_bit_identical_to_their_separate_launches(setup, monkeypatch):
     """front_fused_kernel (2:1 letterbox + stem + layer 1 in one launch), c2f16_fused_kernel (layer 2: cv1, 3x3,
     3x3 + shortcut, cv2 in one launch) and the 32-channel blocks at P3 (layer 4: c2f32_head_kernel + c2f32_tail_kernel for
-    its six convolutions; layer 15: cv1 + c2f32_tail_kernel) against the separate launches (AVHOT_YOLO_NO_FUSE, read per
-    forward): every element of the outputs of layers 1, 2, 4 and 15, borders included, on frames with different content,
+    its six convolutions; layer 15: cv1 + c2f32_tail_kernel) and the virtual Upsample + Concat in front of layers 12 and 15
+    (no upsample launch: cv1 fetches the half-resolution source itself) against the separate launches (AVHOT_YOLO_NO_FUSE, read
+    per forward): every element of the outputs of layers 1, 2, 4, 12 and 15, borders included, on frames with different content,
     in a batch large enough that persistent workgroups walk more than one tile -- and the detections at the end."""
     import torch
     Y, R, frame, feats, model, _ = setup
@@ -261,14 +262,16 @@ def test_fused_kernels_are_bit_identical_to_their_separate_launches(setup, monke
         m.forward_device(m._frames)
         torch.cuda.synchronize()
         return (m.tensor(1, image=None), m.tensor(2, image=None), m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(),
-                m._conf.cpu().numpy().copy(), m.tensor(4, image=None), m.tensor(15, image=None))
+                m._conf.cpu().numpy().copy(), m.tensor(4, image=None), m.tensor(15, image=None), m.tensor(12, image=None))
     fused = run()
     monkeypatch.setenv("AVHOT_YOLO_NO_FUSE", "1")
     unfused = run()
     monkeypatch.delenv("AVHOT_YOLO_NO_FUSE")
     assert fused[0].shape == (len(frames), 96, 160, 32) and fused[0].any() and fused[1].shape == (len(frames), 96, 160, 32) and fused[1].any()
     assert fused[5].shape == (len(frames), 48, 80, 64) and fused[5].any() and fused[6].shape == (len(frames), 48, 80, 64) and fused[6].any()
-    for k, name in ((0, "layer 1"), (1, "layer 2"), (5, "layer 4"), (6, "layer 15")):
+    assert fused[7].shape == (len(frames), 24, 40, 128) and fused[7].any()
+    # (layers 12 and 15 also cover the virtual Upsample + Concat: their cv1 reads the half-resolution source directly)
+    for k, name in ((0, "layer 1"), (1, "layer 2"), (5, "layer 4"), (7, "layer 12"), (6, "layer 15")):
         assert np.array_equal(fused[k].view(np.uint32), unfused[k].view(np.uint32)), (name, int((fused[k] != unfused[k]).sum()))
     assert np.array_equal(fused[2], unfused[2]) and np.array_equal(fused[3], unfused[3]) and np.array_equal(fused[4], unfused[4])
     # the keep_logits model (three launches, network input and stem map kept) gives the same layer-1 map as the production path

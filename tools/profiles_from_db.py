@@ -10,6 +10,21 @@ import sqlite3
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "multimodal_autonomous_driving_perception_and_planning_amd", "csrc")
+
+
+def stamp(kernel_file):
+    """What bench.py needs to decide whether a counter value still describes the kernel it is printed next to: the commit the
+    profile was taken at and a hash of the kernel's source file (bench.py drops `traffic` to null when the file has changed)."""
+    import hashlib
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        commit = ""
+    h = hashlib.sha256(open(os.path.join(CSRC, kernel_file), "rb").read()).hexdigest()[:16]
+    return {"measured_at_commit": commit, "kernel_source": "csrc/" + kernel_file, "kernel_source_sha256_16": h, "round": tag}
 
 
 def db_of(name):
@@ -86,7 +101,9 @@ for k in sorted(set(fe) | set(wr)):
     if any(k.startswith(t) for t in pixel_kernels):
         pix_total += f + w_
 lane["pixel_stage_hbm_bytes_per_px"] = round(pix_total / px, 4)
-json.dump(lane, open(os.path.join(dst, "lane_pmc.json"), "w"), indent=1)
+lane.update(stamp("lane.hip"))
+if lane["kernels"]:
+    json.dump(lane, open(os.path.join(dst, "lane_pmc.json"), "w"), indent=1)
 
 # ---- planner -----------------------------------------------------------------------------------------------------------------
 fe, wr = counters("plan_fetch"), counters("plan_write")
@@ -95,10 +112,10 @@ for k in fe:
         states = 64 * 256
         f, w_ = 2.0 * fe[k]["FETCH_SIZE"] * 1024.0, wr[k]["WRITE_SIZE"] * 1024.0
         json.dump({"kernel": k, "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, each with --kernel-trace only) -- "
-                                          "python3 tools/kbench.py --streams 64 --window 256 --stages plan --reps 2, MI355X, round 2",
+                                          "python3 tools/kbench.py --streams 64 --window 256 --stages plan --reps 2, MI355X, " + tag,
                    "states_per_launch": states, "WRITE_SIZE_KiB": wr[k]["WRITE_SIZE"], "FETCH_SIZE_KiB_raw": fe[k]["FETCH_SIZE"],
                    "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)", "hbm_bytes_per_launch": int(f + w_),
-                   "hbm_bytes_per_state": round((f + w_) / states), "algorithmic_bytes_per_state": 51660},
+                   "hbm_bytes_per_state": round((f + w_) / states), "algorithmic_bytes_per_state": 51660, **stamp("planner.hip")},
                   open(os.path.join(dst, "planner_pmc.json"), "w"), indent=2)
 
 # ---- tracker (the headline step's longest kernel: latency-bound, its HBM traffic is reported for completeness) --------------------
@@ -108,10 +125,10 @@ for k in fe:
         frames = 64 * 256
         f, w_ = 2.0 * fe[k]["FETCH_SIZE"] * 1024.0, wr[k]["WRITE_SIZE"] * 1024.0
         json.dump({"kernel": k, "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, each with --kernel-trace only) -- "
-                                          "python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2, MI355X, round 2",
+                                          "python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2, MI355X, " + tag,
                    "frames_per_launch": frames, "WRITE_SIZE_KiB": wr[k]["WRITE_SIZE"], "FETCH_SIZE_KiB_raw": fe[k]["FETCH_SIZE"],
                    "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)", "hbm_bytes_per_launch": int(f + w_),
-                   "hbm_bytes_per_frame": round((f + w_) / frames, 1), "algorithmic_bytes_per_frame": 4776},
+                   "hbm_bytes_per_frame": round((f + w_) / frames, 1), "algorithmic_bytes_per_frame": 4776, **stamp("tracker.hip")},
                   open(os.path.join(dst, "tracker_pmc.json"), "w"), indent=2)
 
 # ---- YOLO: MFMA busy ------------------------------------------------------------------------------------------------------------
@@ -119,7 +136,7 @@ mf = counters("yolo_mfma")
 tot_busy = tot_act = 0.0
 per = {}
 for k, q in mf.items():
-    if "conv" not in k or not q.get("GRBM_GUI_ACTIVE"):
+    if not any(t in k for t in ("conv", "c2f", "front_fused")) or not q.get("GRBM_GUI_ACTIVE"):      # every kernel with MFMA convolutions
         continue
     busy, act = q.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * q["launches"], q["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 * q["launches"]
     tot_busy += busy
@@ -128,6 +145,6 @@ for k, q in mf.items():
 if tot_act:
     json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE -- python3 tools/ybench.py --batch 64 --reps 3; "
                          "busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
-               "overall_mfma_busy_percent": round(100.0 * tot_busy / tot_act, 2), "kernels": per},
+               "overall_mfma_busy_percent": round(100.0 * tot_busy / tot_act, 2), "kernels": per, **stamp("yolo.hip")},
               open(os.path.join(dst, "yolo_mfma_pmc.json"), "w"), indent=1)
 print("profiles written to", dst)
