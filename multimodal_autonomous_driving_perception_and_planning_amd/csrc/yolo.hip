@@ -1697,11 +1697,13 @@ __device__ __forceinline__ bool nms_over(const float4 a, float aa, const float4 
 }
 
 // Greedy NMS over the sorted candidates, one workgroup of NMS_WAVES waves per image.  Candidates are taken 64
-// at a time (lane = candidate).  Every wave tests the chunk against its share of the boxes kept so far
-// (kept box k belongs to wave k % NMS_WAVES; boxes broadcast from LDS) and the per-wave survivor masks are
-// AND-ed; wave 0 then lets the chunk resolve itself in order with a ballot loop over its still-alive
-// members and appends the survivors.  Identical decisions to box-at-a-time greedy suppression (a box is
-// dropped iff an earlier KEPT box overlaps it), with two barriers per 64 candidates instead of per kept box.
+// at a time (lane = candidate).  A chunk is tested against the boxes kept so far (kept box k belongs to one wave; boxes
+// broadcast from LDS; per-wave survivor masks AND-ed) and then resolves itself in order, in wave 0, with a ballot loop over its
+// still-alive members.  The two halves are PIPELINED: while wave 0 resolves chunk c, the other fifteen waves already test chunk
+// c + 1 against everything kept BEFORE chunk c; once chunk c's survivors are known, all sixteen test chunk c + 1 against just
+// those (at most 64 boxes, four per wave).  Identical decisions to box-at-a-time greedy suppression (a box is dropped iff an
+// earlier KEPT box overlaps it); per chunk the critical path is max(resolve, test) + a short increment instead of their sum
+// (5 us -> 3.5 us; with random weights ~27 chunks are walked to keep 300 boxes).
 constexpr int NMS_WAVES = 16;
 __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     int A, int max_det, float iou_thres, const float* __restrict__ sbox, const int* __restrict__ scount,
@@ -1712,29 +1714,27 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     float4* kbx = reinterpret_cast<float4*>(nms_smem);                      // kept boxes [max_det]
     float* kar = reinterpret_cast<float*>(kbx + max_det);                   // their areas
     int* kix = reinterpret_cast<int*>(kar + max_det);                       // their position in the sorted list
-    __shared__ unsigned long long amask[NMS_WAVES];
+    __shared__ unsigned long long m_old[NMS_WAVES], m_new[NMS_WAVES];       // survivor masks of the chunk wave 0 resolves next
     __shared__ int s_kept;
     const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, cnt = scount[n];
     const float4* sb = reinterpret_cast<const float4*>(sbox) + (size_t)n * A;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) m_old[wid] = ~0ull, m_new[wid] = ~0ull;                  // chunk 0: nothing kept yet
     int kept = 0;
-    float4 b = lane < cnt ? sb[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b = lane < cnt ? sb[lane] : zero4;                               // chunk c
+    float4 b1 = lane + 64 < cnt ? sb[lane + 64] : zero4;                    // chunk c + 1
+    __syncthreads();
     for (int base = 0; base < cnt && kept < max_det; base += 64) {
         const int i = base + lane;
-        const bool valid = i < cnt;
-        const float bb = (b.z - b.x) * (b.w - b.y);
-        const int inext = i + 64;                      // next chunk's boxes are in flight during this one
-        const float4 bnext = inext < cnt ? sb[inext] : make_float4(0.f, 0.f, 0.f, 0.f);
-        bool alive = valid;
-        for (int k = wid; k < kept; k += NMS_WAVES)
-            if (nms_over(kbx[k], kar[k], b, bb, iou_thres)) alive = false;
-        const unsigned long long mine = __ballot(alive);
-        if (lane == 0) amask[wid] = mine;
-        __syncthreads();
+        const float bb = (b.z - b.x) * (b.w - b.y), bb1 = (b1.z - b1.x) * (b1.w - b1.y);
+        const float4 b2 = i + 128 < cnt ? sb[i + 128] : zero4;             // chunk c + 2: in flight during this iteration
+        unsigned long long early = ~0ull;
         if (wid == 0) {
-            unsigned long long m = ~0ull;
+            // ---- resolve chunk c -----------------------------------------------------------------------------------------------
+            unsigned long long m = __ballot(i < cnt);
 #pragma unroll
-            for (int w = 0; w < NMS_WAVES; ++w) m &= amask[w];
-            alive = (m >> lane) & 1ull;
+            for (int w = 0; w < NMS_WAVES; ++w) m &= m_old[w] & m_new[w];
+            bool alive = (m >> lane) & 1ull;
             unsigned long long todo = m;
             while (todo) {
                 const int li = __ffsll((long long)todo) - 1;
@@ -1754,10 +1754,25 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
             int nk = kept + __popcll(m);
             nk = nk > max_det ? max_det : nk;
             if (lane == 0) s_kept = nk;
+        } else {
+            // ---- meanwhile: chunk c + 1 against everything kept before chunk c (fifteen waves) -------------------------------------------
+            bool alive1 = true;
+            for (int k = wid - 1; k < kept; k += NMS_WAVES - 1)
+                if (nms_over(kbx[k], kar[k], b1, bb1, iou_thres)) alive1 = false;
+            early = __ballot(alive1);
+        }
+        __syncthreads();                         // chunk c's survivors are in kbx; wave 0 is done reading the masks
+        const int kept1 = s_kept;
+        {   // ---- chunk c + 1 against chunk c's survivors (all waves) ------------------------------------------------------------------
+            bool alive1 = true;
+            for (int k = kept + wid; k < kept1; k += NMS_WAVES)
+                if (nms_over(kbx[k], kar[k], b1, bb1, iou_thres)) alive1 = false;
+            const unsigned long long late = __ballot(alive1);
+            if (lane == 0) m_old[wid] = early, m_new[wid] = late;
         }
         __syncthreads();
-        kept = s_kept;
-        b = bnext;
+        kept = kept1;
+        b = b1, b1 = b2;
     }
     // the detections, all at once (the gathers through sidx would otherwise sit in the chunk loop's critical path)
     for (int pos = threadIdx.x; pos < kept; pos += 64 * NMS_WAVES) {
