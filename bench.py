@@ -583,17 +583,18 @@ def _short(txt, n=140):
 def compact_summary(v):
     """One `also` entry as the driver keeps it: value, time per step, dtype, the dominant stage's roofline, the CPU baseline."""
     if "value" not in v:                                  # per_frame_classes / bev_panels: already small
-        return {k: (_short(x, 160) if isinstance(x, str) else x) for k, x in v.items() if k not in ("kernels", "note")}
+        return {k: x for k, x in v.items() if not isinstance(x, str)}
     out = {"value": v["value"], "unit": v.get("unit"), "ms_per_step": v.get("ms_per_step"), "dtype": v.get("dtype"),
-           "steps": v.get("steps"), "workload": _short(v.get("config", {}).get("workload", ""), 150)}
+           "workload": _short(v.get("config", {}).get("workload", ""), 90)}
     if "us_per_time_step" in v:
         out["us_per_time_step"] = v["us_per_time_step"]
     r = v.get("roofline", {})
-    out["roofline"] = {k: (_short(r[k], 90) if isinstance(r[k], str) else r[k])
+    out["roofline"] = {k: (_short(r[k], 60) if isinstance(r[k], str) else r[k])
                        for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_ms",
                                  "cus_occupied", "mfma_busy_pmc_percent") if k in r}
-    if "hbm_bound_kernel_beside_it" in r:
-        out["roofline"]["hbm_bound_kernel_beside_it"] = r["hbm_bound_kernel_beside_it"]
+    hb = r.get("hbm_bound_kernel_beside_it")
+    if hb and hb.get("kernel") != r.get("kernel"):
+        out["roofline"]["hbm_bound_kernel_beside_it"] = {k: hb[k] for k in ("kernel", "avg_ms", "frac", "traffic") if k in hb}
     if "lane_chain" in v:
         out["lane_chain"] = {k: v["lane_chain"][k] for k in ("avg_ms", "achieved", "frac", "unit")}
         out["stage_ms"] = {k["stage"]: k["avg_ms"] for k in v.get("kernels", [])}
@@ -608,7 +609,10 @@ def compact_summary(v):
 def compact_line(head):
     """The printed line: the headline in full except its long texts, `also` as compact summaries."""
     line = {k: v for k, v in head.items() if k not in ("also", "kernels", "stage_kernels_replaced")}
-    line["kernels"] = [{k: (_short(x, 100) if isinstance(x, str) else x) for k, x in kk.items() if k != "why"} for kk in head.get("kernels", [])]
+    line["kernels"] = [{k: (_short(x, 100) if isinstance(x, str) else x) for k, x in kk.items() if k not in ("why", "peak", "unit", "branch")}
+                       for kk in head.get("kernels", [])]
+    if "roofline" in line and "note" in line["roofline"]:
+        line["roofline"] = dict(line["roofline"], note=_short(line["roofline"]["note"], 120))
     if "cpu_baseline" in line and "sample" in line["cpu_baseline"]:
         line["cpu_baseline"] = dict(line["cpu_baseline"], sample=_short(line["cpu_baseline"]["sample"], 200))
     if "also" in head:

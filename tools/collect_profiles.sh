@@ -3,7 +3,7 @@
 # Counters in passes of their own (FETCH_SIZE and WRITE_SIZE do not fit one pass; never together with --stats/sys traces).
 # Output: gpurun_out/<tag>/<name>/*_results.db (rocpd SQLite) -> tools/profiles_from_db.py turns them into profiles/*.csv / *.json
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -12,6 +12,7 @@ pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr -d $OUT/$n
 trace bench_config4 python3 bench.py --no-also --no-cpu-baseline
 trace bench_config3 python3 bench.py --no-also --no-cpu-baseline --workload config3
 trace bench_config2 python3 bench.py --no-also --no-cpu-baseline --workload config2 --steps 4 --warmup 1 --window 32768
+trace bench_config4_w1 python3 bench.py --no-also --no-cpu-baseline --workload config4 --window 1 --steps 500 --warmup 50
 trace lane_S64 python3 tools/lbench.py --reps 5
 trace yolo_b64 python3 tools/ybench.py --batch 64 --reps 5
 pmc lane_fetch FETCH_SIZE python3 tools/lbench.py --reps 2

@@ -62,7 +62,7 @@ def counters(name):
     return out
 
 
-for nm in ("bench_config4", "bench_config3", "bench_config2", "lane_S64", "yolo_b64"):
+for nm in ("bench_config4", "bench_config4_w1", "bench_config3", "bench_config2", "lane_S64", "yolo_b64"):
     stats(nm, "%s_%s_kernel_stats.csv" % (tag, nm))
 
 # ---- YOLO: launch-by-launch timeline of the last forward of the trace (tools/ytimeline.py) ---------------------------------
