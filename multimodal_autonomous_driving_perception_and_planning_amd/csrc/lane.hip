@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -699,6 +700,9 @@ __device__ __forceinline__ unsigned pk_mulu(unsigned a, unsigned short k) {
     const u16x2_t kk = {k, k};
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) * kk);
 }
+__device__ __forceinline__ unsigned pk_mulv(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) * __builtin_bit_cast(u16x2_t, b));
+}
 __device__ __forceinline__ unsigned pk_shru(unsigned a, int n) {
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, a) >> (unsigned short)n);
 }
@@ -878,6 +882,289 @@ __global__ void __launch_bounds__(256) front_stream(const uint8_t* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 16; ++q) tot += lh[q * 256 + tid];
     if (tot) atomicAdd(&hist[(size_t)s * 256 + tid], tot);
+}
+
+// ---- packed-strip front end (front_pack): the same one-pass BGR -> nm pipeline as front_stream, rebuilt around what a
+// calibration of the vector pipe (tools/wvalu.hip) and in-kernel clocks (tools/ltime.py) showed about front_stream:
+//  * it is bound by vector-instruction issue (196 per 4-pixel row, ~3.5 cycles each with six waves per SIMD), so every
+//    instruction that could go went: weights x4 so that gray is byte 2 of the accumulator (no shifts, one v_perm packs a
+//    pair), x + 2y and x*6 + y as v_pk_mad_u16 (hipcc emits shift + add), the rounding constant inside a v_add3, LDS
+//    histogram addresses by v_mad_u32_u16 straight from the packed halves, row addresses as a scalar base + a per-lane
+//    32-bit offset (no 64-bit multiply-adds, no register copies behind the loads), and all tests that only concern the
+//    image's border rows / columns moved out of the steady state: border rows are fixed up under scalar branches, border
+//    columns exist only in the EDGE instantiation that the first strip and the remainder waves run;
+//  * 1280 columns are 320 four-pixel chunks = 5 strips of 62 + 10: the sixth strip used a whole wave for 10 chunks.
+//    Remainder chunks of the same band of FIVE frames now share one wave (12 lanes each incl. their two halo lanes), so a
+//    band of five frames takes 26 waves instead of 30;
+//  * equal-priority waves are served oldest first: the six waves of a SIMD finished one after the other (30 ... 114 us for
+//    identical work) and the tail ran at one to three waves per SIMD, where an instruction costs 3.6-5.4 cycles instead of
+//    2.5.  A wave now lowers its own priority as it advances (3 -> 2 -> 1 -> 0), so whoever is behind outranks whoever is
+//    ahead and all waves of a SIMD finish together; the priority is raised by the kernel's first instruction because a
+//    newly placed wave (priority 0) would otherwise starve in its prologue.
+struct FrontGeo {
+    int S, nb, nfull, rem, G, nc;            // frames, bands, full strips per band, remainder chunks, frames per remainder wave, histogram copies in LDS
+};
+
+template <int K>
+__device__ __forceinline__ unsigned pk_madk(unsigned a, unsigned c) {       // a * K + c per 16-bit half
+    unsigned d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_min1(unsigned a) {                  // min(a, 1) per half
+    unsigned d;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    return d;
+}
+__device__ __forceinline__ unsigned mad_lo16x4(unsigned p, unsigned base) {  // (p & 0xFFFF) * 4 + base
+    unsigned d;
+    asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(d) : "v"(p), "v"(base));
+    return d;
+}
+__device__ __forceinline__ unsigned mad_hi16x4(unsigned p, unsigned base) {  // (p >> 16) * 4 + base
+    unsigned d;
+    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(p), "v"(base));
+    return d;
+}
+__device__ __forceinline__ void lds_add(unsigned byte_addr, unsigned v) {
+    asm volatile("ds_add_u32 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
+}
+
+template <bool KEEP_BLUR, int FROWS, bool TIMED, int ABL = 0>
+__global__ void __launch_bounds__(64, 5) front_pack(const uint8_t* __restrict__ bgr, int h, int w, FrontGeo geo, uint8_t* __restrict__ blur,
+                                                 uint8_t* __restrict__ nm, unsigned* __restrict__ hist) {
+    // One wave per workgroup: 5328 equal work items on 256 CUs are 20.8 per CU -- in four-wave workgroups that was 5 or 6
+    // workgroups per CU and the CUs with six set the kernel's time (100 us against 79 on the others).
+    extern __shared__ unsigned lh[];                                     // geo.nc histogram copies of 256 bins
+    __builtin_amdgcn_s_setprio(3);
+    unsigned long long tm0 = 0, tr0 = 0, sect = 0;
+    if (TIMED) tm0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    const int lane = threadIdx.x;
+    for (int i = lane; i < geo.nc * 256; i += 64) lh[i] = 0;
+    const int C = w >> 2, bx = (int)blockIdx.x, per_frame = geo.nb * geo.nfull;
+    const bool full = bx < geo.S * per_frame;
+    int band, cidx, s_l, s0, hcopy;
+    bool halo, lane_on = true, edge;
+    if (full) {
+        s0 = __builtin_amdgcn_readfirstlane(bx / per_frame);            // (integer division runs on the vector unit: bring the
+        const int item = bx - s0 * per_frame;                            // wave-uniform results back to scalar registers)
+        band = __builtin_amdgcn_readfirstlane(item / geo.nfull);
+        const int strip = item - band * geo.nfull;
+        cidx = 62 * strip - 1 + lane, s_l = s0, halo = lane == 0 || lane == 63, hcopy = lane % geo.nc;
+        edge = strip == 0 || 62 * strip + 62 >= C - 1;
+    } else {
+        const int rb = bx - geo.S * per_frame, grp = __builtin_amdgcn_readfirstlane(rb / geo.nb), gw = geo.rem + 2;
+        band = rb - grp * geo.nb;
+        const int gi = lane / gw, li = lane - gi * gw, cpg = geo.nc / geo.G;
+        s0 = grp * geo.G, s_l = s0 + gi;
+        lane_on = gi < geo.G && s_l < geo.S;
+        cidx = 62 * geo.nfull - 1 + li, halo = li == 0 || li == gw - 1;
+        hcopy = lane_on ? gi * cpg + li % cpg : 0;
+        edge = true;
+    }
+    const bool wave_on = true;
+    band = __builtin_amdgcn_readfirstlane(band), s0 = __builtin_amdgcn_readfirstlane(s0);
+    edge = __builtin_amdgcn_readfirstlane((int)edge) != 0;
+    const bool xin = lane_on && cidx >= 0 && cidx < C;
+    const bool out_lane = xin && !halo;
+    const bool at_left = xin && cidx == 0, at_right = xin && cidx == C - 1;
+    const unsigned lane_mask = xin ? 0xFFFFFFFFu : 0u;
+    const unsigned xs = xin ? 4u * (unsigned)cidx : 0u, sl = lane_on ? (unsigned)s_l : (unsigned)s0;
+    const unsigned voff_in = sl * ((unsigned)h * (unsigned)w * 3u) + xs * 3u;      // host checked: S*h*w*3 < 2^32
+    const unsigned voff_out = sl * ((unsigned)h * (unsigned)w) + xs;
+    const unsigned hbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)lh + (unsigned)hcopy * 1024u;      // LDS byte address of this lane's histogram copy
+    const int yb = band * FROWS;
+    if (wave_on && yb < h) {
+        const int y_end = (yb + FROWS < h ? yb + FROWS : h);
+        const int r_first = yb - 4, r_last = y_end + 3;
+        const unsigned pitch = (unsigned)w * 3u;
+        auto run = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
+            unsigned H02[3] = {0, 0, 0}, H13[3] = {0, 0, 0}, U02[3] = {0, 0, 0}, U13[3] = {0, 0, 0};
+            unsigned P02[3] = {0, 0, 0}, P13[3] = {0, 0, 0}, PE[3] = {0, 0, 0};
+            unsigned M02[3] = {0, 0, 0}, M13[3] = {0, 0, 0}, ME[3] = {0, 0, 0};
+            unsigned HZ02[3] = {0, 0, 0}, HZ13[3] = {0, 0, 0}, VT02[3] = {0, 0, 0}, VT13[3] = {0, 0, 0}, NG02[3] = {0, 0, 0},
+                     NG13[3] = {0, 0, 0};
+            unsigned fa[3], fb[3], fc[3];                                // BGR rows in flight: slot r % 3 holds row r, loaded two rows ahead (three: 12 spilled registers, 137 us)
+            // kernel-argument base + one 32-bit offset (row term scalar): a single add and a load with a scalar base
+            auto fetch_at = [&](unsigned ys, unsigned& a, unsigned& b, unsigned& c) {
+                if (ABL & 2) { a = ys * 0x01010101u + (unsigned)lane * 0x00030201u; b = a ^ 0x05050505u; c = a + 0x00010203u; return; }
+                const unsigned* p = reinterpret_cast<const unsigned*>(bgr + (voff_in + ys * pitch));
+                a = p[0], b = p[1], c = p[2];
+            };
+            auto fetch = [&](int yy, unsigned& a, unsigned& b, unsigned& c) {
+                fetch_at((unsigned)reflect101_once(yy < r_last ? yy : r_last, h), a, b, c);
+            };
+            fetch(r_first, fa[0], fb[0], fc[0]);
+            fetch(r_first + 1, fa[1], fb[1], fc[1]);
+            // One row of the pipeline; k = r mod 3 is a compile-time ring slot.  STEADY rows lie strictly inside the band and
+            // the image: every row test is known (histogram and store on, no border fix-ups, no reflection of the fetched
+            // row), which is what takes the scalar unit's ~70 instructions per row out of the loop.
+            auto row = [&](auto steady_c, auto k_c, const int r) {
+                constexpr bool STEADY = decltype(steady_c)::value;
+                constexpr int k = decltype(k_c)::value, k1 = (k + 2) % 3, k2 = (k + 1) % 3;        // slots of rows r-1 and r-2 (= r+1 mod 3)
+                // ---- gray row r.  Weights x 4: acc = 4 * (1868 B + 9617 G + 4899 R + 8192), gray = byte 2 of acc ----
+                const unsigned a = fa[k], b = fb[k], c = fc[k];          // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                if (STEADY) fetch_at((unsigned)(r + 2), fa[k1], fb[k1], fc[k1]);        // slot (r + 2) % 3 = the one consumed last trip
+                else fetch(r + 2, fa[k1], fb[k1], fc[k1]);
+                const u16x2_t wbg = {7472, 38468};
+                auto acc = [&](unsigned bg_pair, unsigned rr) {
+                    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, bg_pair), wbg, (unsigned)__umul24(19596u, rr) + 32768u, false);
+                };
+                const unsigned a0 = acc(__builtin_amdgcn_perm(0u, a, 0x0C010C00u), (a >> 16) & 255u);
+                const unsigned a1 = acc(__builtin_amdgcn_perm(b, a, 0x0C040C03u), (b >> 8) & 255u);
+                const unsigned a2 = acc(__builtin_amdgcn_perm(0u, b, 0x0C030C02u), c & 255u);
+                const unsigned a3 = acc(__builtin_amdgcn_perm(0u, c, 0x0C020C01u), c >> 24);
+                const unsigned G02 = __builtin_amdgcn_perm(a2, a0, 0x0C060C02u), G13 = __builtin_amdgcn_perm(a3, a1, 0x0C060C02u);
+                // ---- horizontal 1 4 6 4 1 ----
+                unsigned gprev = dpp_prev_u32(hi_hi(G02, G13));          // the previous lane's (g2, g3) = columns x-2, x-1
+                unsigned gnext = dpp_next_u32(lo_lo(G02, G13));          // the next lane's (g0, g1) = columns x+4, x+5
+                if (EDGE) {
+                    const unsigned R21 = hi_lo(G02, G13);                // reflect-101: columns -2,-1 and w,w+1 mirror to (g2, g1)
+                    gprev = at_left ? R21 : gprev, gnext = at_right ? R21 : gnext;
+                }
+                const unsigned L2 = lo_lo(gprev, G02), L1 = hi_lo(gprev, G13);          // (g-2, g0), (g-1, g1)
+                const unsigned R2 = hi_lo(G02, gnext), R3 = hi_hi(G13, gnext);          // (g2, g4), (g3, g5)
+                H02[k] = pk_madk<6>(G02, pk_madk<4>(L1 + G13, L2 + R2));                // sums <= 4080 per half: plain adds carry nothing across
+                H13[k] = pk_madk<6>(G13, pk_madk<4>(G02 + R2, L1 + R3));
+                // ---- vertical (1 2 1) twice; blurred row bl = r-2 ----
+                U02[k] = pk_madk<2>(H02[k1], H02[k2] + H02[k]);
+                U13[k] = pk_madk<2>(H13[k1], H13[k2] + H13[k]);
+                const unsigned p02 = pk_shru(pk_madk<2>(U02[k1], U02[k2] + U02[k] + 0x00800080u), 8);
+                const unsigned p13 = pk_shru(pk_madk<2>(U13[k1], U13[k2] + U13[k] + 0x00800080u), 8);
+                P02[k] = p02, P13[k] = p13;
+                const int bl = r - 2;
+                if (STEADY || (bl >= yb && bl < y_end)) {                // this wave owns the blurred row: histogram (+ debug copy)
+                    if (out_lane && !(ABL & 1)) {
+                        if (KEEP_BLUR) *reinterpret_cast<unsigned*>(blur + (voff_out + (unsigned)bl * (unsigned)w)) = p02 | (p13 << 8);
+                        unsigned t0, t1, t2, t3;                         // LDS addresses straight from the packed halves
+                        asm volatile("v_mad_u32_u16 %0, %4, 4, %6\n\tv_mad_u32_u16 %1, %4, 4, %6 op_sel:[1,0,0,0]\n\t"
+                                     "v_mad_u32_u16 %2, %5, 4, %6\n\tv_mad_u32_u16 %3, %5, 4, %6 op_sel:[1,0,0,0]\n\t"
+                                     "ds_add_u32 %0, %7\n\tds_add_u32 %1, %7\n\tds_add_u32 %2, %7\n\tds_add_u32 %3, %7"
+                                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p02), "v"(p13), "v"(hbase), "v"(1u) : "memory");
+                    }
+                }
+                {   // blurred neighbours across the lane border: PE = (column x-1 | column x+4 << 16)
+                    unsigned dp = dpp_prev_u32(p13), dn = dpp_next_u32(p02);            // .hi = o3 of the previous lane, .lo = o0 of the next
+                    if (EDGE) dp = at_left ? (p02 << 16) : dp, dn = at_right ? (p13 >> 16) : dn;     // replicate at the image edge
+                    PE[k] = hi_lo(dp, dn);
+                }
+                // Sobel reads blurred(-1) as blurred(0) and blurred(h) as blurred(h-1) (replicate): rewrite the ring slot
+                // when those rows pass -- two scalar tests per border row instead of six selects on every row
+                if (!STEADY && bl == 0) {
+                    asm volatile("; blurred(-1) := blurred(0)");
+                    P02[k1] = P02[k], P13[k1] = P13[k], PE[k1] = PE[k];
+                }
+                if (!STEADY && bl == h) {
+                    asm volatile("; blurred(h) := blurred(h-1)");
+                    P02[k] = P02[k1], P13[k] = P13[k1], PE[k] = PE[k1];
+                }
+                // ---- Sobel of row ym = r-3 from blurred rows r-4 (slot k2), r-3 (k1), r-2 (k) ----
+                const int ym = r - 3;
+                unsigned long long ts0 = 0;
+                if (TIMED) ts0 = __builtin_amdgcn_s_memtime();
+                {
+                    const unsigned t02 = P02[k2], t13 = P13[k2], te = PE[k2], b02 = P02[k], b13 = P13[k], be = PE[k];
+                    const unsigned c02 = P02[k1], c13 = P13[k1], ce = PE[k1];
+                    const unsigned v02 = pk_madk<2>(c02, t02 + b02), v13 = pk_madk<2>(c13, t13 + b13), ve = pk_madk<2>(ce, te + be);
+                    const unsigned d02 = pk_sub16(b02, t02), d13 = pk_sub16(b13, t13), de = pk_sub16(be, te);
+                    const unsigned dx02 = pk_sub16(v13, lo_lo(ve, v13));                           // V[k+1] - V[k-1] for pixels 0, 2
+                    const unsigned dx13 = pk_sub16(hi_hi(v02, ve), v02);                           //                  for pixels 1, 3
+                    const unsigned dy02 = pk_add16(pk_madk<2>(d02, lo_lo(de, d13)), d13);
+                    const unsigned dy13 = pk_add16(pk_madk<2>(d13, d02), hi_hi(d02, de));
+                    const unsigned ax02 = pk_abs16(dx02), ax13 = pk_abs16(dx13), ay02 = pk_abs16(dy02), ay13 = pk_abs16(dy13);
+                    unsigned m02 = ax02 + ay02, m13 = ax13 + ay13;                                 // <= 2040 per half: plain add
+                    if (EDGE) m02 &= lane_mask, m13 &= lane_mask;                                  // magnitude is 0 outside the image's columns
+                    if (!STEADY && (ym < 0 || ym >= h)) {                                          // ... and outside its rows
+                        asm volatile("; magnitude row outside the image");
+                        m02 = 0, m13 = 0;
+                    }
+                    M02[k] = m02, M13[k] = m13;
+                    ME[k] = hi_lo(dpp_prev_u32(m13), dpp_next_u32(m02));                           // (m of column x-1 | m of column x+4 << 16)
+                    // direction classes: see front_stream
+                    const unsigned t02q = pk_shru(pk_madk<53>(ax02, pk_shru(pk_mulu(ax02, 5), 8)), 7);
+                    const unsigned t13q = pk_shru(pk_madk<53>(ax13, pk_shru(pk_mulu(ax13, 5), 8)), 7);
+                    HZ02[k] = opaque(pk_sar15(pk_add16(ay02, ~t02q)));                              // |gy| - t22 - 1 < 0
+                    HZ13[k] = opaque(pk_sar15(pk_add16(ay13, ~t13q)));
+                    VT02[k] = opaque(pk_sar15(pk_sub16(pk_madk<2>(ax02, t02q), ay02)));             // t22 + 2|gx| - |gy| < 0
+                    VT13[k] = opaque(pk_sar15(pk_sub16(pk_madk<2>(ax13, t13q), ay13)));
+                    NG02[k] = opaque(pk_sar15(dx02 ^ dy02)), NG13[k] = opaque(pk_sar15(dx13 ^ dy13));              // gradient signs differ
+                }
+                if (TIMED) {
+                    asm volatile("" :: "v"(NG13[k]), "v"(VT13[k]), "v"(HZ13[k]), "v"(ME[k]));
+                    sect += __builtin_amdgcn_s_memtime() - ts0;
+                }
+                // ---- NMS of row yo = r-4: magnitude rows r-5 (slot k2), r-4 (k1), r-3 (k); class masks of row r-4 (k1) ----
+                const int yo = r - 4;
+                if (STEADY || (yo >= yb && yo < y_end)) {
+                    const unsigned mT02 = M02[k2], mT13 = M13[k2], mTE = ME[k2], mC02 = M02[k1], mC13 = M13[k1], mCE = ME[k1],
+                                   mB02 = M02[k], mB13 = M13[k], mBE = ME[k];
+                    const unsigned l02 = lo_lo(mCE, mC13), r13 = hi_hi(mC02, mCE);
+                    const unsigned ul02 = lo_lo(mTE, mT13), ur13 = hi_hi(mT02, mTE), dl02 = lo_lo(mBE, mB13), dr13 = hi_hi(mB02, mBE);
+                    const unsigned hz02 = HZ02[k1], hz13 = HZ13[k1], vt02 = VT02[k1], vt13 = VT13[k1], ng02 = NG02[k1], ng13 = NG13[k1];
+                    const unsigned n1a = bsel(hz02, l02, bsel(vt02, mT02, bsel(ng02, mT13, ul02)));
+                    const unsigned n1b = bsel(hz13, mC02, bsel(vt13, mT13, bsel(ng13, ur13, mT02)));
+                    const unsigned n2a = bsel(hz02, mC13, bsel(vt02, mB02, bsel(ng02, dl02, mB13)));
+                    const unsigned n2b = bsel(hz13, r13, bsel(vt13, mB13, bsel(ng13, mB02, dr13)));
+                    const unsigned ea = pk_minu(pk_subsat(mC02, n1a), pk_subsat(pk_sub16(mC02, hz02 | vt02), n2a));
+                    const unsigned eb = pk_minu(pk_subsat(mC13, n1b), pk_subsat(pk_sub16(mC13, hz13 | vt13), n2b));
+                    const unsigned ca = pk_minu(pk_shru(mC02, 1), 0x00FF00FFu);
+                    const unsigned cb = pk_minu(pk_shru(mC13, 1), 0x00FF00FFu);
+                    const unsigned oa = pk_mulv(ca, pk_min1(ea)), ob = pk_mulv(cb, pk_min1(eb));
+                    if ((ABL & 4) ? (out_lane && (oa ^ ob) == 0x12345678u) : out_lane) *reinterpret_cast<unsigned*>(nm + (voff_out + (unsigned)yo * (unsigned)w)) = oa | (ob << 8);
+                }
+            };
+            const int n_trips = (r_last - r_first + 3) / 3, trip_p2 = r_first + 3 * (n_trips / 2),
+                      trip_p1 = r_first + 3 * ((n_trips * 4) / 5), trip_p0 = r_first + 3 * (n_trips - 1);
+            int r0 = r_first;
+            auto trip = [&](auto steady_c, const int rr) {
+                if (rr == trip_p2) __builtin_amdgcn_s_setprio(2);
+                if (rr == trip_p1) __builtin_amdgcn_s_setprio(1);
+                if (rr == trip_p0) __builtin_amdgcn_s_setprio(0);
+                row(steady_c, std::integral_constant<int, 0>{}, rr);
+                row(steady_c, std::integral_constant<int, 1>{}, rr + 1);
+                row(steady_c, std::integral_constant<int, 2>{}, rr + 2);
+            };
+            // rows r0 .. r0+2 are STEADY when yb + 4 <= r0 (store and histogram on) and r0 + 2 <= min(y_end + 1, h - 3) (still on,
+            // fetched row r + 2 inside the image); the first three trips fill the pipeline
+            const int r_hi = (y_end + 1 < h - 3 ? y_end + 1 : h - 3), r_lo = r_first + 9;
+#pragma nounroll
+            for (;;) {
+                const int rr = __builtin_amdgcn_readfirstlane(r0);       // keeps the row counter, and every test on it, on the scalar unit
+                if (rr > r_last) break;
+                if (rr >= r_lo && rr + 2 <= r_hi) trip(std::true_type{}, rr);
+                else trip(std::false_type{}, rr);
+                r0 = rr + 3;
+            }
+        };
+        if (edge) run(std::true_type{});
+        else run(std::false_type{});
+    }
+    if (TIMED) {
+        const unsigned long long tm1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(blur) + (size_t)bx * 4;
+            dbg[0] = tm1 - tm0, dbg[1] = tr1 - tr0, dbg[2] = tr0;
+            dbg[3] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+                     ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 15) << 32) | (sect << 36);
+        }
+    }
+    // the wave's own LDS operations complete in order: its histogram is final here
+    if (full) {
+        for (int bin = lane; bin < 256; bin += 64) {
+            unsigned tot = 0;
+            for (int q = 0; q < geo.nc; ++q) tot += lh[q * 256 + bin];
+            if (tot) atomicAdd(&hist[(size_t)s0 * 256 + bin], tot);
+        }
+    } else {
+        const int cpg = geo.nc / geo.G;
+        for (int gi = 0; gi < geo.G && s0 + gi < geo.S; ++gi)
+            for (int bin = lane; bin < 256; bin += 64) {
+                unsigned tot = 0;
+                for (int q = 0; q < cpg; ++q) tot += lh[(gi * cpg + q) * 256 + bin];
+                if (tot) atomicAdd(&hist[(size_t)(s0 + gi) * 256 + bin], tot);
+            }
+    }
 }
 
 // candidate / strong bits of 16 map bytes.  NM: the fused front end's non-maximum-suppressed magnitudes against the
@@ -2373,12 +2660,38 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         const bool fused = streamp && fastp && !getenv("AVHOT_LANE_TWO_PASS");
         if (fused) {
             const char* fe = getenv("AVHOT_LANE_FROWS");
-            const int fr = fe ? atoi(fe) : 45;                       // measured at 720p, 64 frames: 45 rows 122 us, 72 rows 128, 90 rows 123
+            const int fr = fe ? atoi(fe) : 48;                       // front_stream at 720p, 64 frames: 45 rows 122 us, 72 rows 128, 90 rows 123
             // a few frames per launch (the per-frame class calls): short bands, so that a frame is hundreds of waves instead of 96
-            const int frows = (stages & 1) ? 72 : (fe ? (fr == 72 ? 72 : (fr == 90 ? 90 : (fr == 15 ? 15 : 45))) : (n_streams <= 8 ? 15 : 45));
-            const dim3 fgrid((((w + SW - 1) / SW) * ((h + frows - 1) / frows) + 3) / 4, 1, n_streams);     // waves = strips x bands
+            const int frows = (stages & 1) ? 72 : (fe ? (fr == 72 ? 72 : (fr == 90 ? 90 : (fr == 15 ? 15 : (fr == 48 ? 48 : 45)))) : (n_streams <= 8 ? 15 : 48));
+            const int sfrows = frows == 48 ? 45 : frows;           // front_stream has no 48-row instantiation
+            const dim3 fgrid((((w + SW - 1) / SW) * ((h + sfrows - 1) / sfrows) + 3) / 4, 1, n_streams);     // front_stream: waves = strips x bands
+            const bool packed = (unsigned long long)n_streams * h * w * 3ull < (1ull << 32) && !getenv("AVHOT_LANE_STRIP_FRONT");
+            if (packed) {
+                // work geometry of front_pack: full strips of 62 chunks, the remainder chunks of G frames share one wave
+                FrontGeo g{};
+                const int C = w >> 2;
+                g.S = n_streams, g.nb = (h + frows - 1) / frows, g.nfull = C / 62, g.rem = C - 62 * g.nfull;
+                g.G = g.rem ? 64 / (g.rem + 2) : 0;
+                if (g.G > 16) g.G = 16;
+                g.nc = g.G > 6 ? g.G : 6;                              // 6 KB of LDS per wave: 26 waves fit a CU
+                const int ngr = g.G ? (n_streams + g.G - 1) / g.G : 0;
+                const dim3 pgrid((unsigned)(n_streams * g.nb * g.nfull + ngr * g.nb));      // one wave per workgroup
+                const size_t lds = (size_t)g.nc * 1024;
+                const bool timed = getenv("AVHOT_LANE_TIMED") != nullptr && !(stages & 1);
+                if (stages & 1) hipLaunchKernelGGL((front_pack<true, 72, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (timed && frows == 48 && getenv("AVHOT_ABL") && atoi(getenv("AVHOT_ABL")) == 1) hipLaunchKernelGGL((front_pack<false, 48, true, 1>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (timed && frows == 48 && getenv("AVHOT_ABL") && atoi(getenv("AVHOT_ABL")) == 2) hipLaunchKernelGGL((front_pack<false, 48, true, 2>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (timed && frows == 48 && getenv("AVHOT_ABL") && atoi(getenv("AVHOT_ABL")) == 6) hipLaunchKernelGGL((front_pack<false, 48, true, 6>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (timed && frows == 48 && getenv("AVHOT_ABL") && atoi(getenv("AVHOT_ABL")) == 7) hipLaunchKernelGGL((front_pack<false, 48, true, 7>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (timed && frows == 48) hipLaunchKernelGGL((front_pack<false, 48, true>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (frows == 48) hipLaunchKernelGGL((front_pack<false, 48, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (frows == 45) hipLaunchKernelGGL((front_pack<false, 45, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (frows == 90) hipLaunchKernelGGL((front_pack<false, 90, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else if (frows == 15) hipLaunchKernelGGL((front_pack<false, 15, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+                else hipLaunchKernelGGL((front_pack<false, 72, false>), pgrid, dim3(64), lds, st, bgr, h, w, g, blur, map, hist);
+            } else
             if (stages & 1) hipLaunchKernelGGL((front_stream<true, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
-            else if (frows == 45) hipLaunchKernelGGL((front_stream<false, 45>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
+            else if (frows == 45 || frows == 48) hipLaunchKernelGGL((front_stream<false, 45>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else if (frows == 90) hipLaunchKernelGGL((front_stream<false, 90>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else if (frows == 15) hipLaunchKernelGGL((front_stream<false, 15>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
             else hipLaunchKernelGGL((front_stream<false, 72>), fgrid, dim3(256), 0, st, bgr, h, w, blur, map, hist);
