@@ -997,6 +997,7 @@ __global__ void __launch_bounds__(64, 5) front_pack(const uint8_t* __restrict__ 
             };
             fetch(r_first, fa[0], fb[0], fc[0]);
             fetch(r_first + 1, fa[1], fb[1], fc[1]);
+            const unsigned flat_count = 4u * (unsigned)__popcll(__ballot(out_lane));
             // One row of the pipeline; k = r mod 3 is a compile-time ring slot.  STEADY rows lie strictly inside the band and
             // the image: every row test is known (histogram and store on, no border fix-ups, no reflection of the fetched
             // row), which is what takes the scalar unit's ~70 instructions per row out of the loop.
@@ -1035,8 +1036,14 @@ __global__ void __launch_bounds__(64, 5) front_pack(const uint8_t* __restrict__ 
                 P02[k] = p02, P13[k] = p13;
                 const int bl = r - 2;
                 if (STEADY || (bl >= yb && bl < y_end)) {                // this wave owns the blurred row: histogram (+ debug copy)
-                    if (out_lane && !(ABL & 1)) {
-                        if (KEEP_BLUR) *reinterpret_cast<unsigned*>(blur + (voff_out + (unsigned)bl * (unsigned)w)) = p02 | (p13 << 8);
+                    // A row whose 248 pixels all have one value (sky, flat surfaces) would be 4 x 62 adds to ONE bin -- the
+                    // slowest case for LDS atomics, which serialise per address: one lane adds 248 instead.
+                    const unsigned v1 = (unsigned)__builtin_amdgcn_readlane((int)p02, 1);
+                    const bool flat = full && (v1 & 0xFFFFu) == (v1 >> 16) && __ballot(out_lane && (p02 != v1 || p13 != v1)) == 0ull;
+                    if (KEEP_BLUR && out_lane) *reinterpret_cast<unsigned*>(blur + (voff_out + (unsigned)bl * (unsigned)w)) = p02 | (p13 << 8);
+                    if (flat && !(ABL & 1)) {
+                        if (lane == 1) lds_add(mad_lo16x4(p02, hbase), flat_count);
+                    } else if (out_lane && !(ABL & 1)) {
                         unsigned t0, t1, t2, t3;                         // LDS addresses straight from the packed halves
                         asm volatile("v_mad_u32_u16 %0, %4, 4, %6\n\tv_mad_u32_u16 %1, %4, 4, %6 op_sel:[1,0,0,0]\n\t"
                                      "v_mad_u32_u16 %2, %5, 4, %6\n\tv_mad_u32_u16 %3, %5, 4, %6 op_sel:[1,0,0,0]\n\t"
