@@ -658,6 +658,24 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
                        n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, \
                        det2trk, fc)
     if (rep) {
+        // A window of frames is a long per-stream latency chain on one CU per stream; whatever else lands on that CU competes
+        // with it for issue slots and for the CU's memory pipeline.  In the batched step the HBM-bound planner runs on the
+        // other stream: claiming (almost) the whole LDS keeps its workgroups (38 KB each) off the tracker's 64 CUs -- config 4
+        // 0.380 -> 0.352 ms per step (100 KB: no change, two planner workgroups still fit; 125 / 150 KB: 0.357 / 0.352).
+        // AVHOT_TRACKER_LDS_KB overrides (0 = only what the kernel needs).
+        const char* pad_env = getenv("AVHOT_TRACKER_LDS_KB");
+        const size_t want = pad_env ? (size_t)atoi(pad_env) * 1024 : (n_frames >= 16 ? (size_t)150 * 1024 : 0);
+        const size_t lds_need = lds;
+        if (want > lds_need && want <= 160 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tracker_kernel<false, 8, REPW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((tracker_kernel<false, 8, REPW>), dim3(n_streams), dim3(tcap * REPW), want, as_stream(stream), *cfg,
+                               n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk, fc);
+        } else
         AV_TRK_LAUNCH(false, 8, REPW);
     } else if (tcap == 64) {
         if (dcap <= 8) AV_TRK_LAUNCH(false, 8, 1);

@@ -328,7 +328,7 @@ class PerceptionLoop:
         # SURVEY 8d's 7*W*H per frame assumed the blurred image goes out to memory and back; the fused front end keeps it
         # in registers, so the chain as a whole is priced on 7*W*H and this stage on what it really needs
         self.lane_pixel_bytes_per_px = 5
-        self.lane_pixel_kernels = ("front_stream (gray+blur+hist+Sobel+NMS) + thresholds + ccl_tile + ccl_border + "
+        self.lane_pixel_kernels = ("front_pack (gray+blur+hist+Sobel+NMS) + thresholds + ccl_tile + ccl_border + "
                                    "finalize_fast + compact_box")
         self.frame_idx = 0
         self._lanes_pending = False

@@ -82,9 +82,9 @@ lane = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_*
                   "64 frames of 1280x720 per launch; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)",
         "pixels_per_launch": px, "kernels": {}}
 pix_total = 0.0
-pixel_kernels = ("front_stream", "thresholds_kernel", "ccl_tile_kernel", "ccl_border_kernel", "finalize_fast", "compact_box_kernel")
+pixel_kernels = ("front_pack", "front_stream", "thresholds_kernel", "ccl_tile_kernel", "ccl_border_kernel", "finalize_fast", "compact_box_kernel")
 for k in sorted(set(fe) | set(wr)):
-    if not any(t in k for t in ("front_stream", "thresholds", "ccl_", "finalize", "compact", "hough", "lane_fit")):
+    if not any(t in k for t in ("front_pack", "front_stream", "thresholds", "ccl_", "finalize", "compact", "hough", "lane_fit")):
         continue
     f = 2.0 * fe.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
     w_ = wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
