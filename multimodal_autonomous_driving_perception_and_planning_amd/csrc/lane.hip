@@ -941,7 +941,15 @@ __global__ void __launch_bounds__(64, 5) front_pack(const uint8_t* __restrict__ 
     if (TIMED) tm0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x;
     for (int i = lane; i < geo.nc * 256; i += 64) lh[i] = 0;
-    const int C = w >> 2, bx = (int)blockIdx.x, per_frame = geo.nb * geo.nfull;
+    const int C = w >> 2, per_frame = geo.nb * geo.nfull;
+    // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with an L2 of its own.  Neighbouring strips share the
+    // 128-byte lines at their seam and neighbouring bands their 8 halo rows, so an XCD takes a CONTIGUOUS eighth of the work
+    // items (8 whole frames of the 64) in dispatch order -- placement is for speed only, any mapping is correct.
+    int bx = (int)blockIdx.x;
+    {
+        const int n_full = geo.S * per_frame, per_xcd = n_full >> 3;
+        if (bx < per_xcd * 8) bx = (bx & 7) * per_xcd + (bx >> 3);
+    }
     const bool full = bx < geo.S * per_frame;
     int band, cidx, s_l, s0, hcopy;
     bool halo, lane_on = true, edge;
