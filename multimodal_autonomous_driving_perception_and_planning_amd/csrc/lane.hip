@@ -1255,6 +1255,8 @@ __device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4
 // A workgroup takes CT_STACK vertically adjacent tiles, all map chunks loaded up front, the non-empty ones resolved one
 // after the other in the same LDS arrays.  Measured at 720p, 64 frames: one tile per workgroup 37 us, four 53 us --
 // the non-empty tiles (lane markings, vehicle outlines) sit above each other and then run serially -- so CT_STACK = 1.
+// (Four tiles a quarter of the frame apart, so that a workgroup's tiles are not non-empty together: 47 us -- the kernel's time
+// is the non-empty tiles' serial LDS work, not its loads.)
 constexpr int CT_STACK = 1;
 template <bool NM>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,

@@ -194,6 +194,52 @@ def test_batched_frames_take_all_three_hough_paths(LaneDetector):
     assert any(4096 < n <= 12288 for n in npts) and any(n > 12288 for n in npts), npts
 
 
+@pytest.mark.parametrize("h,w,S", [(96, 320, 5), (80, 256, 3), (150, 496, 2), (64, 80, 3), (100, 1008, 9), (112, 1280, 11)])
+def test_front_end_work_geometries_in_batches(LaneDetector, h, w, S):
+    """front_pack's work decomposition -- full strips of 62 four-pixel chunks, remainder chunks of G frames sharing a wave,
+    15- or 48-row bands -- at widths that give every case (no full strip; no remainder; 2, 3, 5, 16 frames per remainder
+    wave; frame counts that leave the last group short) through the PRODUCTION call (no debug copies): thresholds and the
+    ROI-masked edge map of every frame of the batch against the oracle."""
+    import ctypes as C
+    import torch
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from oracle.lane_ref import LaneRef
+    rng = np.random.RandomState(h * 7 + w + S)
+    frames = []
+    for s in range(S):
+        f = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        f[:, : w // 3] = (f[:, : w // 3] // 32) * 32 + s                      # plateaus: ties and flat rows as well as noise
+        f[h // 2:, w // 2:] = 40 + 3 * s
+        frames.append(f)
+    MS = 256
+    ctx, L, sh = nat.default_context(0), nat.lib(), nat.stream_handle()
+    dev = torch.device("cuda", 0)
+    bgr = torch.as_tensor(np.stack(frames)).to(dev)
+    ws = torch.empty(int(L.av_lane_workspace_bytes(S, h, w, MS)), dtype=torch.uint8, device=dev)
+    nat.check(L.av_lane_workspace_init(ctx.handle, sh, S, h, w, MS, nat.ptr(ws)))
+    state = torch.zeros(S, 8, dtype=torch.float64, device=dev)
+    poly = torch.zeros(S, 2, 3, dtype=torch.float64, device=dev)
+    pts = torch.zeros(S, 2, 50, 2, dtype=torch.int32, device=dev)
+    info = torch.zeros(S, 8, dtype=torch.int32, device=dev)
+    conf = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+    cfg = nat.LaneCfg(50, 50, 150, MS, 0.7)
+
+    def view(what, dtype, shape):
+        off, nb = C.c_size_t(), C.c_size_t()
+        nat.check(L.av_lane_workspace_view(what, S, h, w, MS, C.byref(off), C.byref(nb)))
+        return ws[off.value:off.value + nb.value].cpu().numpy().view(dtype).reshape(shape)
+
+    for rep in range(2):                                                       # the second call finds the workspace used
+        nat.check(L.av_lane_detect(ctx.handle, sh, C.byref(cfg), S, h, w, nat.ptr(bgr), None, nat.ptr(ws), nat.ptr(state),
+                                   nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), 2))
+        torch.cuda.synchronize()
+        masked, thr = view(3, np.uint8, (S, h, w)), view(4, np.float64, (S, 4))
+        for s in range(S):
+            want = LaneRef().stages(frames[s])
+            assert (thr[s, 0], thr[s, 1], thr[s, 2]) == (want["lo"], want["hi"], want["median"]), (rep, s)
+            assert np.array_equal(masked[s], want["masked"]), (rep, s)
+
+
 def test_fit_rank_cutoff_deviation_is_confined_to_degenerate_inputs(LaneDetector):
     """Known deviation: np.polyfit drops singular values below len(x) * eps of the largest, the
     device solves the scaled normal equations and treats eigenvalue ratios below 1e-12 (singular value ratio 1e-6) as
