@@ -60,6 +60,20 @@ __device__ __forceinline__ float silu(float v) {
     return r;
 }
 
+
+// Progress-ordered wave priority for the persistent tile loops (lane.hip, front_pack, and DESIGN.md section 4 "front end"): waves of
+// equal priority are served oldest first, so workgroups that share a CU finish one after the other and the last one runs at low
+// occupancy.  A workgroup lowers its priority as its tiles go by (3 -> 0); AVHOT_YOLO_PRIO=0 in the environment disables it.
+__device__ int g_yolo_prio = 1;
+__device__ __forceinline__ void progress_prio(int t, int n_tiles) {
+    if (!g_yolo_prio) return;
+    const int q = (4 * t) / (n_tiles > 0 ? n_tiles : 1);            // t runs over the whole grid's tiles: same fraction for every workgroup
+    if (q <= 0) __builtin_amdgcn_s_setprio(3);
+    else if (q == 1) __builtin_amdgcn_s_setprio(2);
+    else if (q == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 template <int MT, int NT>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -468,6 +482,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_ws_kernel(ConvArgs a, int til
         if (RES) rload(t);
     }
     for (; t < n_tiles; t += gridDim.x) {
+        progress_prio(t, n_tiles);
         __syncthreads();                                               // patch of tile t visible
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -600,6 +615,7 @@ __global__ void __launch_bounds__(DEC == 1 ? 128 : 256) conv1x1_ws_kernel(ConvAr
     // a wave's tile: pixels 32 t .. 32 t + 31 (fragment nt: pixels 32 t + 16 nt + l15); tiles strided over all waves of the grid
     const int wstride = gridDim.x * NWV;
     for (int t = blockIdx.x * NWV + wave; t < n_tiles; t += wstride) {
+        progress_prio(t, n_tiles);
         half8 B[KS][NT];
         half8 Bt[NT];
         long pix[NT];
@@ -799,6 +815,7 @@ __global__ void __launch_bounds__(C2F_NTH, 2) c2f16_fused_kernel(C2f16Args a) {
     int t = blockIdx.x;
     if (t < a.n_tiles) gload(t);
     for (; t < a.n_tiles; t += gridDim.x) {
+        progress_prio(t, a.n_tiles);
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();                                       // previous tile done with XY / T1 (and the weights are in)
@@ -1013,6 +1030,7 @@ __global__ void __launch_bounds__(F32_NTH) c2f32_head_kernel(C2f32Args a) {
         n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
     };
     for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        progress_prio(t, a.n_tiles);
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();                                       // previous tile done with XY / T1 (and the weights are in)
@@ -1126,6 +1144,7 @@ __global__ void __launch_bounds__(F32_NTH) c2f32_tail_kernel(C2f32Args a) {
         n = r / a.tiles_y, oy0 = (r % a.tiles_y) * 16, ox0 = tx * 16;
     };
     for (int t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        progress_prio(t, a.n_tiles);
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();
@@ -1358,6 +1377,7 @@ __global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
     int t = blockIdx.x;
     if (t < a.n_tiles) gload(t);
     for (; t < a.n_tiles; t += gridDim.x) {
+        progress_prio(t, a.n_tiles);
         int n, oy0, ox0;
         origin(t, n, oy0, ox0);
         __syncthreads();                                            // the previous tile is done with XL / SL (first trip: weights, zeros)
@@ -2332,6 +2352,15 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     const hipStream_t st_main = st;
     const int B = y.B;
     const bool force_direct = getenv("AVHOT_CONV_DIRECT") != nullptr;      // tuning aid, read once per forward
+    {
+        static int prio_state = -1;                                            // progress_prio() on / off, set once per process
+        const char* e = getenv("AVHOT_YOLO_PRIO");
+        const int want = e ? (atoi(e) != 0) : 1;
+        if (want != prio_state) {
+            AV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_yolo_prio), &want, sizeof(int)));
+            prio_state = want;
+        }
+    }
     size_t first_op = 0;
     {
         const int n = B * y.H * y.W;
