@@ -2083,7 +2083,7 @@ constexpr HoughDraws hough_draws() {
 }
 __device__ const HoughDraws g_draws = hough_draws();
 
-__global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
+__global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
                                                    int* __restrict__ nseg, int* __restrict__ fallback) {
@@ -2095,7 +2095,14 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
     __shared__ float bfx[HB], bfy[HB];
     __shared__ int row_sz[64];
     __shared__ int sh_nb, sh_head, sh_tail, sh_count;
-    const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x;
+    // Second wave = helper.  A lone wave issues one instruction per 5-8 cycles however independent they are (tools/wvalu.hip), and
+    // 47 % of this kernel was the vote phase + the FIFO top-up behind it, 17 % the erase of a fired line.  The helper wave (on another
+    // SIMD) runs every top-up -- beside the votes of the same batch -- and the second direction of every erase; it follows the
+    // main wave through a command word in LDS and a pair of workgroup barriers per command.
+    __shared__ int sh_cmd, sh_er[12], sh_off[64], sh_big;
+    enum { CMD_EXIT = 0, CMD_TOPUP = 1, CMD_ERASE = 2 };
+    const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(accum_all + (size_t)s * NUMANGLE * numrho);
     const int total = npts[s];
@@ -2109,12 +2116,19 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
     // the LDS clears do not depend on the point list: they run while its loads are in flight
-    for (int i = lane; i < HS_ACCW; i += 64) acc[i] = HS_BIAS | (HS_BIAS << 16);
-    for (int i = lane; i < HS_BMW; i += 64) bm[i] = 0;
-    if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups
+    for (int i = (int)threadIdx.x; i < HS_ACCW; i += 128) acc[i] = HS_BIAS | (HS_BIAS << 16);
+    for (int i = (int)threadIdx.x; i < HS_BMW; i += 128) bm[i] = 0;
+    if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups (and both waves)
         give_up();
         return;
     }
+    // (both waves run the set-up below -- same loads, same LDS writes of the same values, same verdicts -- so the helper has the
+    // frame's constants in its own registers; the first barrier comes behind it)
+    auto command = [&](int cmd) {                  // main wave: start the helper on `cmd` (LDS state published by the barrier)
+        if (lane == 0) sh_cmd = cmd;
+        __syncthreads();
+    };
+    auto finish = [&]() { command(CMD_EXIT); };   // main wave: every way out of the kernel releases the helper
     constexpr int NZ_PER = HS_NZ / 64;
     unsigned mine[NZ_PER];
 #pragma unroll
@@ -2156,10 +2170,10 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
     // this lane's accumulator row: the rho range of the points' bounding box for its theta (+-2 bins).  The
     // capacity verdict has to be the same in all HG workgroups of the frame, so each one sizes every theta subset.
     int my_lo = 0, my_base = 0;
-    {
+    bool too_big = false;
+    if (wv == 0) {                                  // (the sizing goes through row_sz in LDS: one wave only, result published below)
         const int half = (numrho - 1) / 2;
         int my_tot = 0;
-        bool too_big = false;
         for (int gg = 0; gg < HG; ++gg) {
             const int t2 = lane * HG + gg;
             int lo = 0, hi = -1;
@@ -2182,15 +2196,18 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
             too_big = too_big || tot > 2 * HS_ACCW;
             if (gg == g) my_lo = lo, my_base = base, my_tot = tot;
         }
-        if (too_big) {
-            give_up();
-            return;
-        }
         if (!th_on) my_lo = 0, my_base = 0;            // idle lanes read cell 0 (they add 0)
         (void)my_tot;
+        sh_off[lane] = my_base - my_lo;
+        if (lane == 0) sh_big = too_big ? 1 : 0;
+    }
+    __syncthreads();                               // set-up complete in both waves, sizing published
+    if (sh_big) {
+        give_up();
+        return;
     }
     // cell index of (this lane's theta, rho of the pixel); idle lanes have ct = sn = 0 and land on cell 0
-    const int my_off = my_base - my_lo;
+    const int my_off = sh_off[lane];
     auto cellf = [&](float fx, float fy) { return __float2int_rn(fx * ct + fy * sn) + my_off; };
     auto vote = [&](int B, unsigned add) -> int {          // count BEFORE the vote (add = 0: a plain read)
         const int sh = (B & 1) * 16;
@@ -2261,7 +2278,46 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         if (lane == 0) sh_tail = sh_tail + nd, sh_count = cnt - nd;
         lds_order();
     };
-    top_up();
+    // ---- the direction-k half of a fired line's erase: clear its live pixels, and for a good line take their votes back -----------
+    // (direction 1 starts behind the fired pixel itself: direction 0 erases that one)
+    auto erase_dir = [&](int k) {
+        const int x0 = sh_er[0], y0 = sh_er[1], dx0 = sh_er[2], dy0 = sh_er[3], xflag = sh_er[4], good = sh_er[5], tend = sh_er[6 + k];
+        const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+        for (int t0 = 0; t0 <= tend; t0 += 64) {
+            const int t = t0 + lane;
+            const int x = x0 + t * dx, y = y0 + t * dy;
+            int i1, j1;
+            if (xflag) j1 = x, i1 = y >> 16; else j1 = x >> 16, i1 = y;
+            const bool on = t <= tend && t >= k && live(j1, i1);
+            unsigned long long bits = __ballot(on);
+            if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
+            if (good) {
+                const float fj = (float)j1, fi = (float)i1;
+                while (bits) {
+                    const int q = __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fj), q));
+                    const float bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fi), q));
+                    if (th_on) unvote(cellf(bj, bi));
+                }
+            }
+            lds_order();
+        }
+    };
+    if (wv == 1) {
+        for (;;) {
+            __syncthreads();                       // a command is published
+            const int cmd = sh_cmd;
+            if (cmd == CMD_EXIT) break;
+            if (cmd == CMD_TOPUP) top_up();
+            else erase_dir(1);
+            __syncthreads();                       // done
+        }
+        return;
+    }
+    auto join = [&]() { __syncthreads(); };       // main wave: the helper's command is done
+    command(CMD_TOPUP);
+    join();
     for (;;) {
         // ---- form the batch: pop up to HB points that are still live ---------------------------------------------
         {
@@ -2272,8 +2328,8 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
                 if (avail == 0) {
                     if (sh_count == 0) break;
                     if (lane == 0) sh_head = head;
-                    lds_order();
-                    top_up();
+                    command(CMD_TOPUP);            // (rare: the FIFO ran dry inside a batch)
+                    join();
                     continue;
                 }
                 const int take = avail < (HB - nb) ? avail : (HB - nb);
@@ -2297,22 +2353,24 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         }
         const int nb = sh_nb;
         if (nb == 0) break;
+        command(CMD_TOPUP);                        // the helper refills the FIFO while this wave votes
         // ---- speculative votes (LDS returning atomics, in order per lane) ---------------------------------------
         int val[HB], cel[HB];
 #pragma unroll
         for (int b = 0; b < HB; ++b) cel[b] = cellf(bfx[b < nb ? b : 0], bfy[b < nb ? b : 0]);
 #pragma unroll
         for (int b = 0; b < HB; ++b) val[b] = vote(cel[b], (b < nb && th_on) ? 1u : 0u);
-        top_up();
         unsigned hm = 0;                                 // per lane: the points whose count reached the threshold here
 #pragma unroll
         for (int b = 0; b < HB; ++b) hm |= val[b] + 1 >= cfg.threshold ? 1u << b : 0u;
         hm = th_on ? hm & (nb == HB ? ~0u : (1u << nb) - 1u) : 0u;
-        const unsigned hitbits = wave_or_u32(hm);
+        const unsigned hitbits = wave_or_u32(hm);          // (one ballot per point instead: 0.514 against 0.471 ms -- 32 dependent scalar tests)
+        join();
         seq += 1;
         unsigned got[HG];
         if (!exchange(0, hitbits, got)) {
             give_up();
+            finish();
             return;
         }
         unsigned hits = 0;
@@ -2333,6 +2391,7 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
             if (b > bs && b < nb && th_on) unvote(cel[b]);
         if (!exchange(1, lbest, got)) {
             give_up();
+            finish();
             return;
         }
         unsigned best = 0;
@@ -2413,30 +2472,13 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
         }
         const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
         const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
-        for (int k = 0; k < 2; ++k) {
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            const int tend = ends[k][2];
-            for (int t0 = 0; t0 <= tend; t0 += 64) {
-                const int t = t0 + lane;
-                const int x = x0 + t * dx, y = y0 + t * dy;
-                int i1, j1;
-                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
-                const bool on = t <= tend && live(j1, i1);
-                unsigned long long bits = __ballot(on);
-                if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
-                if (good) {
-                    const float fj = (float)j1, fi = (float)i1;
-                    while (bits) {
-                        const int q = __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fj), q));
-                        const float bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fi), q));
-                        if (th_on) unvote(cellf(bj, bi));
-                    }
-                }
-                lds_order();
-            }
+        if (lane == 0) {
+            sh_er[0] = x0, sh_er[1] = y0, sh_er[2] = dx0, sh_er[3] = dy0, sh_er[4] = xflag, sh_er[5] = good ? 1 : 0;
+            sh_er[6] = ends[0][2], sh_er[7] = ends[1][2];
         }
+        command(CMD_ERASE);                        // the helper takes direction 1, this wave direction 0
+        erase_dir(0);
+        join();
         if (good) {
             if (g == 0 && lane == 0) {
                 int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
@@ -2445,6 +2487,7 @@ __global__ void __launch_bounds__(64) houghp_shard(int h, int w, int numrho, Hou
             if (++nlines >= cfg.max_segments) break;
         }
     }
+    finish();
     if (g == 0 && lane == 0) nseg[s] = nlines;
 }
 
@@ -2791,7 +2834,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         if (use_shard) {
             hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 32 + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
             AV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3(64), 0, st, h, w, L.numrho, hc, nz, npts, accum,
+            hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3(128), 0, st, h, w, L.numrho, hc, nz, npts, accum,
                                lc->d_trig, segs, nseg, fb);
             AV_LAUNCH_CHECK();
         }
