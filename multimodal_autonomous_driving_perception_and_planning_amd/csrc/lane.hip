@@ -2047,8 +2047,8 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
 
 // ---- L4b': PPHT with theta sharded over HG workgroups per frame, accumulator in LDS ------------------------------
 // houghp_fast is bound by its CU's L1/TA pipeline: every theta lane votes into its own 16-KB row of a global
-// accumulator, one cache line per lane per vote.  Here a frame is handled by HG single-wave workgroups; workgroup
-// g owns theta = HG*lane + g and keeps ONLY those rows, in LDS, over the rho range the points' bounding box can
+// accumulator, one cache line per lane per vote.  Here a frame is handled by HG workgroups (a main wave + a helper wave each,
+// see the kernel); workgroup g owns theta = HG*lane + g and keeps ONLY those rows, in LDS, over the rho range the points' bounding box can
 // reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed two to a word (PPHT's erase also
 // decrements pixels that have not voted yet, so counts go negative; |count| <= number of points <= 4096).  Every
 // workgroup replays the same point list, RNG, FIFO, bitmap and line walks -- all deterministic -- so they stay
@@ -2098,7 +2098,9 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
     // Second wave = helper.  A lone wave issues one instruction per 5-8 cycles however independent they are (tools/wvalu.hip), and
     // 47 % of this kernel was the vote phase + the FIFO top-up behind it, 17 % the erase of a fired line.  The helper wave (on another
     // SIMD) runs every top-up -- beside the votes of the same batch -- and the second direction of every erase; it follows the
-    // main wave through a command word in LDS and a pair of workgroup barriers per command.
+    // main wave through a command word in LDS and a pair of workgroup barriers per command.  (A third wave voting half of a batch's
+    // points beside the main wave was built too, 247 us -- and dropped: the count a vote returns must include exactly the batch's
+    // EARLIER points, which two waves adding concurrently cannot guarantee; 1 run in 5 lost or gained a segment.)
     __shared__ int sh_cmd, sh_er[12], sh_off[64], sh_big;
     enum { CMD_EXIT = 0, CMD_TOPUP = 1, CMD_ERASE = 2 };
     const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
@@ -2122,6 +2124,7 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         give_up();
         return;
     }
+    __syncthreads();                               // the clears are shared between the waves: done before either fills the bitmap
     // (both waves run the set-up below -- same loads, same LDS writes of the same values, same verdicts -- so the helper has the
     // frame's constants in its own registers; the first barrier comes behind it)
     auto command = [&](int cmd) {                  // main wave: start the helper on `cmd` (LDS state published by the barrier)
