@@ -26,7 +26,7 @@ constexpr int TW = 128, TH = 32;            // output tile of the pixel kernels
 constexpr int NUMANGLE = 180;
 
 struct LaneWs {                              // offsets (bytes) into the caller's workspace, per launch
-    size_t blur, map, labels, edges, masked, hist, thr, rowcnt, nz, npts, accum, segs, nseg, total;
+    size_t blur, map, labels, edges, masked, hist, thr, rowcnt, nz, npts, accum, segs, nseg, tedge, total;
     int numrho;
 };
 
@@ -50,6 +50,9 @@ __host__ LaneWs lane_layout(int S, int h, int w, int max_segments) {
     L.accum = o, o = al256(o + (size_t)S * NUMANGLE * L.numrho * 4);
     L.segs = o, o = al256(o + (size_t)S * max_segments * 4 * 4);
     L.nseg = o, o = al256(o + (size_t)S * 4);
+    // per 16 x 256 hysteresis tile: candidate bits of its top and bottom rows (8 + 8 words) and of its first and last columns
+    // (16 + 16 bits), written by the tile pass for the border pass (TE_WORDS words per tile)
+    L.tedge = o, o = al256(o + (size_t)S * ((h + 15) / 16) * ((w + 255) / 256) * 20 * 4);
     L.total = o;
     return L;
 }
@@ -1219,6 +1222,7 @@ __device__ __forceinline__ void chunk_xy(unsigned ci, int cw, float rcw, int& y,
 // with it the edge map are unchanged.  Tile height: 64 rows 90 us, 32 rows 52 us, 16 rows 36 us per 64 frames (LDS per
 // workgroup sets the occupancy, and most tiles hold no candidate at all); the border pass grows from 13 to 17 us.
 constexpr int CT_R = 16, CT_C = 256, CT_CH = CT_C / 16, CT_NCH = CT_R * CT_CH, CT_PX = CT_R * CT_C;
+constexpr int TE_WORDS = 20;        // per tile: [0..7] top row bits, [8..15] bottom row bits, [16] first column (bit r = row r), [17] last column
 
 __device__ __forceinline__ unsigned lds_find(unsigned* lab, unsigned v) {
     unsigned i = v & 0x7fffffffu;
@@ -1260,7 +1264,8 @@ __device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4
 constexpr int CT_STACK = 1;
 template <bool NM>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,
-                                                       const double* __restrict__ thr, unsigned* __restrict__ labels_all) {
+                                                       const double* __restrict__ thr, unsigned* __restrict__ labels_all,
+                                                       unsigned* __restrict__ tedge_all) {
     __shared__ unsigned lab[CT_PX];               // local label: pixel index inside the tile (row * 256 + column), bit 31 = weak
     __shared__ unsigned cm[CT_NCH];               // per 16-pixel chunk: candidate bits | strong bits << 16
     static_assert(CT_NCH == 256, "one chunk per thread and tile");
@@ -1285,7 +1290,11 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
         if (y0 >= h) break;
         unsigned cand, strong;
         map_bits<NM>(vq[t], lo2, hi2, cand, strong);
-        if (__syncthreads_or(cand != 0 ? 1 : 0) == 0) continue;       // no candidate in the tile (also fences the previous tile's reads)
+        unsigned* te = tedge_all + (((size_t)s * gridDim.y * CT_STACK + (y0 / CT_R)) * gridDim.x + blockIdx.x) * TE_WORDS;
+        if (__syncthreads_or(cand != 0 ? 1 : 0) == 0) {               // no candidate in the tile (also fences the previous tile's reads)
+            if (tid < 18) te[tid] = 0;
+            continue;
+        }
         cm[c] = cand | strong << 16;
         {   // own label, or the smallest label of the horizontal run inside the chunk (first strong pixel, else first pixel)
             unsigned rest = cand;
@@ -1302,6 +1311,18 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
             }
         }
         __syncthreads();
+        // the tile's edge candidate bits for the border pass (which then reads 72 bytes per tile instead of whole cache lines of the
+        // map for single bytes at the tile seams: 0.9 B/px of fetches)
+        if (tid < 16) {
+            const int base = tid < 8 ? 2 * tid : (CT_R - 1) * CT_CH + 2 * (tid - 8);
+            te[tid] = (cm[base] & 0xFFFFu) | (cm[base + 1] << 16);
+        } else if (tid < 18) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int rr = 0; rr < CT_R; ++rr)
+                bits |= (tid == 16 ? (cm[rr * CT_CH] & 1u) : ((cm[rr * CT_CH + CT_CH - 1] >> 15) & 1u)) << rr;
+            te[tid] = bits;
+        }
         if (cand) {
             // neighbours outside the tile count as absent here: the border pass makes those links
             const unsigned Lb = cc > 0 ? (cm[c - 1] >> 15) & 1u : 0u, Rb = cc < CT_CH - 1 ? cm[c + 1] & 1u : 0u;
@@ -1340,20 +1361,26 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
 
 // Links across tile borders, with global unions.  blockIdx.y < nbh: the horizontal border above row (blockIdx.y+1)*16,
 // one thread per column; else the vertical border left of column (blockIdx.y-nbh+1)*256, one thread per row.  Same
-// skipping rules as inside the tiles, here with every neighbour's true candidate bit.
-template <bool NM>
-__global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restrict__ map_all, int h, int w, int nbh,
-                                                         const double* __restrict__ thr, unsigned* __restrict__ labels_all) {
+// skipping rules as inside the tiles, with every neighbour's true candidate bit -- read from the edge masks the tile pass
+// left per tile, not from the map (round 2: 52.8 MB of fetches per 64 frames, mostly whole lines for single bytes at the seams;
+// now 6.1 MB).  One thread per border PIXEL on purpose: a thread per 32-bit mask word, which walks its set bits, measured 24 us
+// against 15 -- the pass's time is the unions' dependent global atomics, which want to be spread over threads.
+__global__ void __launch_bounds__(256) ccl_border_kernel(int h, int w, int nbh, const unsigned* __restrict__ tedge_all, int tiles_x,
+                                                         int tiles_y, unsigned* __restrict__ labels_all) {
     const int s = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
-    const uint8_t* m = map_all + (size_t)s * h * w;
     unsigned* lab = labels_all + (size_t)s * h * w;
-    int lo2 = 0, hi2 = 0;
-    if (NM) half_thresholds(thr, s, lo2, hi2);
-    auto cand = [&](int y, int x) { return y >= 0 && x >= 0 && x < w && map_cand<NM>(m[(size_t)y * w + x], lo2); };
+    const unsigned* te = tedge_all + (size_t)s * tiles_y * tiles_x * TE_WORDS;
+    // candidate bit of (row `which` of tile row ty: 0 = its top row, 1 = its bottom row; column x), 0 outside the image
+    auto row_bit = [&](int ty, int which, int x) -> bool {
+        if (x < 0 || x >= w) return false;
+        const unsigned wd = te[((size_t)ty * tiles_x + (x >> 8)) * TE_WORDS + which * 8 + ((x & 255) >> 5)];
+        return (wd >> (x & 31)) & 1u;
+    };
     if ((int)blockIdx.y < nbh) {
-        const int y = ((int)blockIdx.y + 1) * CT_R, x = i;
-        if (x >= w || !cand(y, x)) return;
-        const bool L = cand(y, x - 1), R = cand(y, x + 1), UL = cand(y - 1, x - 1), UC = cand(y - 1, x), UR = cand(y - 1, x + 1);
+        const int ty = (int)blockIdx.y + 1, y = ty * CT_R, x = i;     // the border above tile row ty
+        if (x >= w || !row_bit(ty, 0, x)) return;
+        const bool L = row_bit(ty, 0, x - 1), R = row_bit(ty, 0, x + 1);
+        const bool UL = row_bit(ty - 1, 1, x - 1), UC = row_bit(ty - 1, 1, x), UR = row_bit(ty - 1, 1, x + 1);
         const unsigned me = (unsigned)(y * w + x), up = me - (unsigned)w;
         if (UC) {
             if (!(L && UL)) uf_union(lab, me, up);
@@ -1362,14 +1389,17 @@ __global__ void __launch_bounds__(256) ccl_border_kernel(const uint8_t* __restri
             if (UR && !R) uf_union(lab, me, up + 1u);
         }
     } else {
-        const int x = ((int)blockIdx.y - nbh + 1) * CT_C, y = i;       // A = (y, x), B = (y, x - 1) on the other side
+        const int tx = (int)blockIdx.y - nbh + 1, x = tx * CT_C, y = i;       // A = (y, x), B = (y, x - 1) on the other side
         if (y >= h) return;
-        const bool A = cand(y, x), B = cand(y, x - 1);
+        const int ty = y / CT_R, r = y - ty * CT_R;
+        const unsigned lcol = te[((size_t)ty * tiles_x + tx) * TE_WORDS + 16], rcol = te[((size_t)ty * tiles_x + tx - 1) * TE_WORDS + 17];
+        const bool A = (lcol >> r) & 1u, B = (rcol >> r) & 1u;
         const unsigned a = (unsigned)(y * w + x);
         if (A && B) uf_union(lab, a, a - 1u);
-        if (y % CT_R == 0) return;                                        // the horizontal pass owns the links to the row above
-        if (A && !B && cand(y - 1, x - 1) && !cand(y - 1, x)) uf_union(lab, a, a - (unsigned)w - 1u);       // A's up-left
-        if (B && !A && cand(y - 1, x) && !cand(y - 1, x - 1)) uf_union(lab, a - 1u, a - (unsigned)w);       // B's up-right
+        if (r == 0) return;                                               // the horizontal pass owns the links to the row above
+        const bool Au = (lcol >> (r - 1)) & 1u, Bu = (rcol >> (r - 1)) & 1u;       // (y - 1, x), (y - 1, x - 1)
+        if (A && !B && Bu && !Au) uf_union(lab, a, a - (unsigned)w - 1u);       // A's up-left
+        if (B && !A && Au && !Bu) uf_union(lab, a - 1u, a - (unsigned)w);       // B's up-right
     }
 }
 
@@ -2713,6 +2743,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* accum = (int*)(ws + L.accum);
     int* segs = (int*)(ws + L.segs);
     int* nseg = (int*)(ws + L.nseg);
+    unsigned* tedge = (unsigned*)(ws + L.tedge);
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
     const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0 &&
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
@@ -2780,13 +2811,12 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         int cbox[4] = {0, 0, w >> 4, h}, cbox_rows = h;               // chunk box of the resolve / compaction passes
         if (fastp) {
             const dim3 tgrid((w + CT_C - 1) / CT_C, ((h + CT_R - 1) / CT_R + CT_STACK - 1) / CT_STACK, n_streams);
-            if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
-            else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels);
+            if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge);
+            else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge);
             const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
             if (nbh + nbv > 0) {
                 const dim3 bgrid((span + 255) / 256, nbh + nbv, n_streams);
-                if (fused) hipLaunchKernelGGL(ccl_border_kernel<true>, bgrid, dim3(256), 0, st, map, h, w, nbh, thr, labels);
-                else hipLaunchKernelGGL(ccl_border_kernel<false>, bgrid, dim3(256), 0, st, map, h, w, nbh, thr, labels);
+                hipLaunchKernelGGL(ccl_border_kernel, bgrid, dim3(256), 0, st, h, w, nbh, tedge, (int)tgrid.x, (int)tgrid.y, labels);
             }
             AV_LAUNCH_CHECK();
             // chunk box the resolve pass visits: everything for the debug edge map or a caller-defined ROI, else the
