@@ -754,7 +754,7 @@ constexpr int C2F_OFF_T1 = 400 * C2F_XS, C2F_OFF_W1 = C2F_OFF_T1 + 324 * C2F_TS,
               C2F_OFF_Z = C2F_OFF_Y2 + C2F_NW * 16 * 32, C2F_LDS = C2F_OFF_Z + 64;    // Z: 64 zero bytes
 static_assert(2 * C2F_LDS <= 160 * 1024, "two workgroups per CU");
 
-__global__ void __launch_bounds__(C2F_NTH, 2) c2f16_fused_kernel(C2f16Args a) {
+__global__ void __launch_bounds__(C2F_NTH, 4) c2f16_fused_kernel(C2f16Args a) {      // (second argument = waves per SIMD: 4 = two 8-wave workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     unsigned char* XY = lsm;                                  // [400][32 ch]: input patch, then cv1's output in place
     unsigned char* T1 = lsm + C2F_OFF_T1;                     // [324][16 ch]
@@ -1332,7 +1332,7 @@ constexpr int FR_OFF_S = FR_XR * FR_XC * 8, FR_OFF_W = FR_OFF_S + ((FR_SR * FR_S
               FR_LDS = FR_OFF_LUT + 512;
 constexpr int FR_NTH = 512, FR_TASKS = (FR_XR * (FR_XC / 2) + FR_NTH - 1) / FR_NTH;
 
-__global__ void __launch_bounds__(FR_NTH, 2) front_fused_kernel(FrontArgs a) {
+__global__ void __launch_bounds__(FR_NTH, 4) front_fused_kernel(FrontArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     unsigned char* XL = lsm;                        // [35][68] pixels of 4 halves (R G B 0); column index = X column - (4 ox0 - 3)
     unsigned char* SL = lsm + FR_OFF_S;             // [17 * 33] stem outputs, 16 halves in 48 bytes
