@@ -378,6 +378,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                                   "tracker + 6-state KF + 21-candidate planner%s" % (name, S, W, ", one hipGraph replay per step" if graph else ""),
                       "streams_per_gpu": S, "window": W, "graph": bool(graph), "taggers": bool(a.taggers),
                       "allgather_track_tables": (("per-frame" if xchg.per_frame else "window-end") if xchg is not None else False),
+                      "allgather_impl": (("av_allgather_tracks (RCCL)" if xchg.native else "torch.distributed") if xchg is not None else None),
                       "fused_step": bool(loop.fused_step),
                       "parallelism": "stream-sharded x%d" % world},
            "roofline": roof, "kernels": finish_kernel_list(ks),

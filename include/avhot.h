@@ -173,6 +173,17 @@ size_t av_wire_table_bytes(int tcap);          /* AV_WIRE_HDR_BYTES + tcap * AV_
 int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
                    int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, void* wire);
 
+/* The all-gather itself as a library call on an RCCL communicator (av_allgather_tracks(ctx, ncclComm_t, ...);
+ * the reference has no counterpart).  `comm` is an ncclComm_t: the caller's own, or one made by av_comm_create from a
+ * 128-byte ncclUniqueId that rank 0 obtained with av_comm_unique_id and handed to the other ranks by any means (the Python class
+ * broadcasts it with torch.distributed).  librccl is opened with dlopen at the first of these calls: the library has no link-time
+ * dependency on it, and a process that never gathers never loads it.
+ *   send [bytes_per_rank] this rank's packed tables; recv [world * bytes_per_rank] every rank's, in rank order; stream-ordered. */
+int av_comm_unique_id(void* id128);
+int av_comm_create(av_ctx* ctx, const void* id128, int rank, int world, void** comm);
+int av_comm_destroy(void* comm);
+int av_allgather_tracks(av_ctx* ctx, void* comm, av_stream_t stream, const void* send, void* recv, size_t bytes_per_rank);
+
 /* ---- E1-E3: vehicle state estimator ------------------------------------------------------------
  * Replaces VehicleStateEstimator.predict/update/step/_extract_state
  * (src/state_estimation/vehicle_state.py:68-198) incl. filterpy's predict/update equations. */

@@ -103,6 +103,10 @@ _SIGS = [
                                     C.c_int, vp, vp, vp, vp]),
     ("av_wire_table_bytes", C.c_size_t, [C.c_int]),
     ("av_pack_tracks", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    ("av_comm_unique_id", C.c_int, [vp]),
+    ("av_comm_create", C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("av_comm_destroy", C.c_int, [vp]),
+    ("av_allgather_tracks", C.c_int, [vp, vp, vp, vp, vp, C.c_size_t]),
     ("av_kf_reset", C.c_int, [vp, vp, C.c_int, vp]),
     ("av_kf_step", C.c_int, [vp, vp, C.POINTER(KfCfg), C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     ("av_planner_configure", C.c_int, [vp, C.POINTER(PlannerCfg)]),

@@ -7,6 +7,9 @@
 // and 32-B writes.
 #include "common.h"
 
+#include <dlfcn.h>
+#include <cstring>
+
 namespace {
 
 // one thread per (table, row); tables are [n_streams][n_sel] selected frames of snap[n_streams][n_frames][tcap]
@@ -49,6 +52,44 @@ __global__ void __launch_bounds__(256) pack_tracks_kernel(int n_streams, int n_f
     reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = o;
 }
 
+// ---- RCCL, opened on demand (no link-time dependency) ---------------------------------------------------------------------
+struct NcclId { char b[128]; };                     // ncclUniqueId
+struct Rccl {
+    void* so = nullptr;
+    int (*get_unique_id)(NcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, NcclId, int) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.so) break;
+        }
+        if (r.so) {
+            r.get_unique_id = reinterpret_cast<int (*)(NcclId*)>(dlsym(r.so, "ncclGetUniqueId"));
+            r.comm_init_rank = reinterpret_cast<int (*)(void**, int, NcclId, int)>(dlsym(r.so, "ncclCommInitRank"));
+            r.comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(r.so, "ncclCommDestroy"));
+            r.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.so, "ncclAllGather"));
+            r.error_string = reinterpret_cast<const char* (*)(int)>(dlsym(r.so, "ncclGetErrorString"));
+        }
+    }
+    return (r.so && r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather) ? &r : nullptr;
+}
+#define AV_RCCL(call, what)                                                                                          \
+    do {                                                                                                             \
+        const int rc_ = (call);                                                                                      \
+        if (rc_ != 0) {                                                                                              \
+            av_set_error("%s: %s", what, R->error_string ? R->error_string(rc_) : "RCCL error");                     \
+            return AV_EHIP;                                                                                          \
+        }                                                                                                            \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -67,6 +108,43 @@ int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames,
     hipLaunchKernelGGL(pack_tracks_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_streams, n_frames, tcap,
                        frame_lo, n_sel, stream0, frame0, snap, snap_n, (uint8_t*)wire);
     AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+int av_comm_unique_id(void* id128) {
+    AV_REQUIRE(id128, AV_EINVAL, "av_comm_unique_id: null argument");
+    Rccl* R = rccl();
+    AV_REQUIRE(R, AV_ESTATE, "av_comm_unique_id: librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+    AV_RCCL(R->get_unique_id(reinterpret_cast<NcclId*>(id128)), "ncclGetUniqueId");
+    return AV_OK;
+}
+
+int av_comm_create(av_ctx* ctx, const void* id128, int rank, int world, void** comm) {
+    AV_REQUIRE(ctx && id128 && comm, AV_EINVAL, "av_comm_create: null argument");
+    AV_REQUIRE(world >= 1 && rank >= 0 && rank < world, AV_EINVAL, "av_comm_create: rank %d of %d", rank, world);
+    Rccl* R = rccl();
+    AV_REQUIRE(R, AV_ESTATE, "av_comm_create: librccl could not be opened");
+    AV_HIP(hipSetDevice(ctx->device));
+    NcclId id;
+    std::memcpy(&id, id128, sizeof(id));
+    AV_RCCL(R->comm_init_rank(comm, world, id, rank), "ncclCommInitRank");
+    return AV_OK;
+}
+
+int av_comm_destroy(void* comm) {
+    if (!comm) return AV_OK;
+    Rccl* R = rccl();
+    AV_REQUIRE(R, AV_ESTATE, "av_comm_destroy: librccl could not be opened");
+    AV_RCCL(R->comm_destroy(comm), "ncclCommDestroy");
+    return AV_OK;
+}
+
+int av_allgather_tracks(av_ctx* ctx, void* comm, av_stream_t stream, const void* send, void* recv, size_t bytes_per_rank) {
+    AV_REQUIRE(ctx && comm && send && recv, AV_EINVAL, "av_allgather_tracks: null argument");
+    AV_REQUIRE(bytes_per_rank > 0, AV_EINVAL, "av_allgather_tracks: nothing to gather");
+    Rccl* R = rccl();
+    AV_REQUIRE(R, AV_ESTATE, "av_allgather_tracks: librccl could not be opened");
+    AV_RCCL(R->all_gather(send, recv, bytes_per_rank, 1 /* ncclUint8 */, comm, as_stream(stream)), "ncclAllGather");
     return AV_OK;
 }
 

@@ -18,6 +18,9 @@ Two modes (bytes per rank per step at S = 64 streams, tcap = 64, 2064 B per tabl
 With W = 1 and the one-launch step (av_hot_step) the step kernel writes the wire tables itself, straight into the send buffer
 (TrackTableExchange.begin_step() before the step, exchange() after it): per-frame tables, no pack launch.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -120,7 +123,10 @@ class TrackTableExchange:
     code path runs synchronously with the torch statement of the pack kernel.
     per_frame=False: the end-of-window table of every stream; True: all W tables of the window."""
 
-    def __init__(self, loop, world, rank, group=None, per_frame=False):
+    def __init__(self, loop, world, rank, group=None, per_frame=False, native=None):
+        """native=True (or AVHOT_NATIVE_ALLGATHER=1): the gather is the library call av_allgather_tracks on an RCCL
+        communicator of its own (made from a ncclUniqueId that rank 0 broadcasts through torch.distributed) instead of
+        torch.distributed.all_gather_into_tensor; GPU tensors only."""
         self.loop, self.world, self.rank, self.group, self.per_frame = loop, world, rank, group, per_frame
         S, tcap, dev = loop.S, loop.tcap, loop.dev
         self.n_sel = loop.W if per_frame else 1
@@ -130,9 +136,25 @@ class TrackTableExchange:
         self.gpu = torch.device(dev).type == "cuda"
         self.send = [torch.zeros(S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
         self.recv = [torch.zeros(world * S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
+        if native is None:
+            native = os.environ.get("AVHOT_NATIVE_ALLGATHER", "0") == "1"
+        self.native = bool(native) and self.gpu
+        self.nccl = None
         if self.gpu:
             self.comm = torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event() for _ in range(2)]
+        if self.native:
+            L = nat.lib()
+            uid = (C.c_ubyte * 128)()
+            if rank == 0:
+                nat.check(L.av_comm_unique_id(uid))
+            if world > 1:
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0, group=group)
+                uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            h = C.c_void_p()
+            nat.check(L.av_comm_create(loop.ctx.handle, uid, rank, world, C.byref(h)))
+            self.nccl = h
         self.done = [None, None]
         self.k = 0                      # steps exchanged so far; step k uses buffer k & 1
         # window 1 with the one-launch step (HotLoop.fused_step): the step kernel itself writes the wire tables, straight into
@@ -169,7 +191,11 @@ class TrackTableExchange:
         self.ready[b].record(loop.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])
-            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
+            if self.native:
+                nat.check(nat.lib().av_allgather_tracks(self.loop.ctx.handle, self.nccl, nat.stream_handle(self.comm),
+                                                        nat.ptr(self.send[b]), nat.ptr(self.recv[b]), self.bytes_per_step))
+            else:
+                dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             ev = torch.cuda.Event()
             ev.record(self.comm)
             self.done[b] = ev
@@ -185,3 +211,10 @@ class TrackTableExchange:
     def synchronize(self):
         if self.gpu:
             self.comm.synchronize()
+
+    def close(self):
+        """Destroys the native communicator (if any); the object must not exchange afterwards."""
+        if self.nccl is not None:
+            self.synchronize()
+            nat.check(nat.lib().av_comm_destroy(self.nccl))
+            self.nccl = None
