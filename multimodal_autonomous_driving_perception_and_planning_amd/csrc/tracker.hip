@@ -22,6 +22,7 @@
 // only when a frame has REP detections -- keeps complete rows (ids, ages, hits, confidences, history rings)
 // and does every global write; the others carry just what column ownership needs: boxes, miss counters
 // and the row count, kept in step by the same matches, births and order-preserving compactions.
+// Windows (PIPE): the complete rows move to a ninth wave that trails the column waves by one frame -- see tracker_body.
 #include "common.h"
 
 namespace {
@@ -87,19 +88,32 @@ __device__ __forceinline__ void lds_sync() {
 // registers; DREG == 0: generic path for larger dcap (best candidate recomputed when its column is taken).
 // (a device function of the stream index s: tracker_kernel runs it with s = blockIdx.x, the fused time-step kernel of step.hip
 // with its own workgroup-to-stream map; smem = the workgroup's dynamic LDS)
-template <bool MULTIWAVE, int DREG, int REP>
+// PIPE (replica kernel, windows): a ninth wave holds the complete rows and runs ONE FRAME BEHIND the eight column waves.  What a
+// frame does to the table is decided by the light state alone (boxes, miss counters, row count); ids, ages, confidences, history
+// rings, the snapshot rows and det2trk are derived from those decisions.  tools/ktime.py: the wave that kept the complete rows was
+// the critical path of every frame (2 820 of 2 900 cycles busy; the others waited 600-800 cycles at the barrier for it).  The
+// column waves now publish a frame's decisions (every row's matched column + the taken columns, 65 bytes, by wave 0) and go on;
+// the ninth wave applies them after the next frame's barrier -- the same barrier, no other synchronisation -- from a double-
+// buffered detection chunk.  Same arithmetic on the same values in the same order per row: results are bit-identical.
+template <bool MULTIWAVE, int DREG, int REP, bool TIMED = false, int PIPE = 0>
 __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
                                const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
-                               int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem) {
+                               int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
+                               const unsigned long long wave_map = 0xFEDCBA9876543210ull) {
     constexpr bool REPL = REP > 1;
     static_assert(!(REPL && MULTIWAVE), "replica waves hold the whole table: tcap must be 64");
     static_assert(REP == 1 || REP == 8, "the exchange buffers are laid out for 8 columns");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    static_assert(!PIPE || REPL, "the trailing wave belongs to the replica kernel");
+    // wave_map: role (column / trailing wave) of every hardware wave, a nibble each.  Waves go to the CU's four SIMDs round-robin, and a
+    // lone wave on a SIMD runs its dependent chain fastest: the map pairs the columns that usually hold a detection (0, 1, 2) with the
+    // ones that rarely do, and keeps the trailing wave(s) away from them (launch_replicas).  Identity for every other use.
+    const int lane = threadIdx.x & 63;
+    const int wid = REPL ? (int)((wave_map >> (4 * __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6))) & 15ull) : (int)(threadIdx.x >> 6);
+    const int tid = REPL ? wid * 64 + lane : (int)threadIdx.x;
     const int row = REPL ? lane : tid;                 // table row this thread holds
-    const bool full = !REPL || wid == REP - 1;         // this wave keeps complete rows and writes the outputs
+    const bool full = !REPL || wid == (PIPE ? REP : REP - 1);    // this wave keeps complete rows and writes the outputs
     // per replica: Shared | stage[tcap];  then the detection chunk;  then (REPL) the exchange buffers
     const size_t sh_bytes = (sizeof(Shared) + 63) & ~size_t(63);
     const size_t rep_bytes = sh_bytes + (size_t)tcap * sizeof(av_track_row);
@@ -107,16 +121,27 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
     Shared& sh = *reinterpret_cast<Shared*>(rbase);
     av_track_row* stage = reinterpret_cast<av_track_row*>(rbase + sh_bytes);
     // detections of a chunk of FC frames: n[FC] | box[FC][dcap][4] | cls[FC][dcap] | conf[FC][dcap] | area[FC][dcap]
-    unsigned char* chunk = smem + (size_t)REP * rep_bytes;
+    unsigned char* chunk = smem + (size_t)(REP + PIPE) * rep_bytes;
     const int FC = chunk_frames;
-    int* c_n = reinterpret_cast<int*>(chunk);
-    int* c_box = c_n + ((FC + 3) & ~3);
-    int* c_cls = c_box + (size_t)FC * dcap * 4;
-    double* c_conf = reinterpret_cast<double*>(c_cls + (((size_t)FC * dcap + 1) & ~size_t(1)));
-    double* c_area = c_conf + (size_t)FC * dcap;       // (x2-x1)*(y2-y1) of every staged detection, exact in f64
+    const size_t chunk_sz = ((size_t)((FC + 3) & ~3) * 4 + (size_t)FC * dcap * 16 + (((size_t)FC * dcap + 1) & ~size_t(1)) * 4 +
+                             (size_t)FC * dcap * 16 + 15) & ~size_t(15);
+    int *c_n, *c_box, *c_cls;
+    double *c_conf, *c_area;                           // area: (x2-x1)*(y2-y1) of every staged detection, exact in f64
+    auto set_chunk = [&](unsigned char* base) {
+        c_n = reinterpret_cast<int*>(base);
+        c_box = c_n + ((FC + 3) & ~3);
+        c_cls = c_box + (size_t)FC * dcap * 4;
+        c_conf = reinterpret_cast<double*>(c_cls + (((size_t)FC * dcap + 1) & ~size_t(1)));
+        c_area = c_conf + (size_t)FC * dcap;
+    };
+    set_chunk(chunk);
+    int cpar = 1;                                      // PIPE: chunk buffer in use (toggled at every chunk start)
     // exchange, one buffer per frame parity: cand[64 rows][8 cols] bytes | count[8] | any[8] | winner[8]
     constexpr int XB = 576;
-    unsigned char* xchg = reinterpret_cast<unsigned char*>(c_area + (size_t)FC * dcap);
+    unsigned char* xchg = chunk + (PIPE ? 2 : 1) * chunk_sz;
+    // PIPE: a frame's decisions for the trailing wave, by frame parity: matched column of every row (signed byte) | taken columns
+    constexpr int RB = 80;
+    signed char* rec = reinterpret_cast<signed char*>(xchg + 2 * XB);
 
     // a dependent per-frame chain: let these few waves issue ahead of throughput kernels sharing the SIMD
     __builtin_amdgcn_s_setprio(3);
@@ -175,6 +200,189 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
     };
     if (REPL && n_frames > 0) prefetch((size_t)s * n_frames, n_frames < FC ? n_frames : FC);
     int fl = -1;                               // frame within the staged chunk
+    // TIMED (AVHOT_TRACKER_TIMED, tools/ktime.py): cycles of every wave of stream 0 by phase, summed over the window, left in det2trk
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (TIMED) tprev = __builtin_amdgcn_s_memtime();
+#define TRK_STAMP(k)                                                   \
+    if (TIMED) {                                                       \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();  \
+        tacc[k] += tn_ - tprev;                                        \
+        tprev = tn_;                                                   \
+    }
+    // ---- what a frame does to the table once its association is known (matched column of every row, taken columns) ----------------
+    // (a lambda: the frame loop below runs it in place; with PIPE the trailing wave runs it one frame late)
+    auto apply = [&](int matched_j, unsigned long long used, int nd, const int* dbox, const int* dcls, const double* dconf, size_t sf) {
+        const bool active = row < T;
+        // ---- matched / missed (:182-211) ---------------------------------------------------------
+        if (active) {
+            if (matched_j >= 0) {
+                const int4 nb4 = *reinterpret_cast<const int4*>(dbox + matched_j * 4);
+                if (full) {
+                    const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
+                    const double ncx = (double)(nb4.x + nb4.z) / 2.0, ncy = (double)(nb4.y + nb4.w) / 2.0;
+                    r.conf = dconf[matched_j];
+                    r.age += 1, r.hits += 1;
+                    double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
+                    *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
+                    r.vx = (float)(ncx - ocx), r.vy = (float)(ncy - ocy);
+                    r.hlen += 1;
+                    r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
+                    sh.d2t[matched_j] = r.id;
+                }
+                r.x1 = nb4.x, r.y1 = nb4.y, r.x2 = nb4.z, r.y2 = nb4.w;
+                r.misses = 0;
+            } else {
+                r.age += 1, r.misses += 1;
+            }
+        }
+
+        TRK_STAMP(4)                                        // matched / missed
+        // ---- births (:214-225) ------------------------------------------------------------------
+        const unsigned long long dmask = nd >= 64 ? ~0ull : ((1ull << nd) - 1ull);
+        const unsigned long long unm = ~used & dmask;
+        const int nb = __popcll(unm);
+        int nb_fit = nb;
+        if (T + nb > tcap) nb_fit = tcap - T, status |= 1;
+        if (nb > 0 && !full) {
+            // light copy: the new rows' boxes only
+            if (row >= T && row < T + nb_fit) {
+                const int4 b4 = *reinterpret_cast<const int4*>(dbox + nth_set_bit(unm, row - T) * 4);
+                r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
+                r.misses = 0;
+            }
+            T += nb_fit;
+        } else if (nb > 0) {
+            // rank of each free history slot; the b-th birth takes the b-th free slot
+            {
+                const unsigned word = sh.slot_bits[row >> 5];
+                const bool is_free = !((word >> (row & 31)) & 1u);
+                int below = __popc(~word & ((1u << (row & 31)) - 1u));
+                for (int w = 0; w < (row >> 5); ++w) below += 32 - __popc(sh.slot_bits[w]);
+                if (is_free && below < nb_fit) sh.birth_slot[below] = row;
+            }
+            if (row < nd && ((unm >> row) & 1ull)) {
+                const int b = __popcll(unm & ((1ull << row) - 1ull));
+                sh.d2t[row] = next_id + b;
+            }
+            lds_sync<MULTIWAVE>();
+            if (row >= T && row < T + nb_fit) {
+                const int b = row - T;
+                const int j = nth_set_bit(unm, b);
+                r.id = next_id + b;
+                r.x1 = dbox[j * 4 + 0], r.y1 = dbox[j * 4 + 1], r.x2 = dbox[j * 4 + 2], r.y2 = dbox[j * 4 + 3];
+                r.cls = dcls[j];
+                r.conf = dconf[j];
+                r.age = 0, r.hits = 1, r.misses = 0;
+                r.slot = sh.birth_slot[b];
+                r.hlen = 1;
+                r.hpos = (L == 1) ? 0 : 1;
+                r.vx = 0.f, r.vy = 0.f;
+                double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
+                *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
+                atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
+            }
+            next_id += nb;
+            T += nb_fit;
+        }
+
+        TRK_STAMP(5)                                        // births
+        // ---- deaths (:228-233): order-preserving compaction --------------------------------------
+        const bool live_row = row < T;
+        const bool dead = live_row && (r.misses > cfg.max_age);
+        int any_dead;
+        if (MULTIWAVE) {
+            if (row == 0) sh.misc[0] = 0;
+            lds_sync<MULTIWAVE>();
+            if (dead) sh.misc[0] = 1;
+            lds_sync<MULTIWAVE>();
+            any_dead = sh.misc[0];
+        } else {
+            any_dead = __ballot(dead) != 0ull;
+        }
+        if (any_dead) {
+            const bool keep = live_row && !dead;
+            const unsigned long long kb = __ballot(keep);
+            int pos = __popcll(kb & ((1ull << lane) - 1ull));
+            int total = __popcll(kb);
+            if (MULTIWAVE) {
+                if (lane == 0) sh.w_cnt[wid] = total;
+                lds_sync<MULTIWAVE>();
+                total = 0;
+                for (int w = 0; w < nwaves; ++w) {
+                    if (w < wid) pos += sh.w_cnt[w];
+                    total += sh.w_cnt[w];
+                }
+            }
+            if (!full) {
+                // light copy: boxes and miss counters move down the same way
+                int* ls = reinterpret_cast<int*>(stage);
+                if (keep) {
+                    *reinterpret_cast<int4*>(ls + pos * 8) = make_int4(r.x1, r.y1, r.x2, r.y2);
+                    ls[pos * 8 + 4] = r.misses;
+                }
+                lds_sync<MULTIWAVE>();
+                T = total;
+                if (row < T) {
+                    const int4 b4 = *reinterpret_cast<const int4*>(ls + row * 8);
+                    r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
+                    r.misses = ls[row * 8 + 4];
+                }
+            } else {
+                if (dead) atomicAnd(&sh.slot_bits[r.slot >> 5], ~(1u << (r.slot & 31)));
+                if (keep) {
+                    av_track_row g;
+                    g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
+                    g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
+                    g.flags = r.hpos, g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;      // flags carries hpos through the staging only
+                    stage[pos] = g;
+                }
+                lds_sync<MULTIWAVE>();
+                T = total;
+                if (row < T) {
+                    const av_track_row g = stage[row];
+                    r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
+                    r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
+                    r.hpos = g.flags;
+                    r.conf = g.conf, r.vx = g.vx, r.vy = g.vy;
+                }
+            }
+        }
+
+        TRK_STAMP(6)                                        // deaths
+        // ---- per-frame outputs --------------------------------------------------------------------
+        if (full) emit(sf);
+        lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
+        TRK_STAMP(7)                                        // outputs
+    };
+    if (PIPE && wid == REP) {
+        // ---- the trailing wave: the column waves' barriers of frame f, then frame f - 1 applied to the complete rows ------------------
+        int pl = -1, gl = -1;
+        for (int f = 0; f <= n_frames; ++f) {
+            if (f < n_frames) {
+                pl = (pl + 1 == FC) ? 0 : pl + 1;
+                if (pl == 0) {                             // chunk hand-over of the column waves (buffer of the other parity)
+                    lds_sync<true>();
+                    lds_sync<true>();
+                }
+            }
+            lds_sync<true>();                              // frame f's exchange barrier (f == n_frames: the closing one)
+            TRK_STAMP(2)
+            if (f == 0) continue;
+            const int g = f - 1;
+            const size_t sg = (size_t)s * n_frames + g;
+            gl = (gl + 1 == FC) ? 0 : gl + 1;
+            if (gl == 0) cpar ^= 1, set_chunk(chunk + (size_t)cpar * chunk_sz);
+            int nd = c_n[gl];
+            nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
+            frame_count += 1;
+            if (row < dcap) sh.d2t[row] = -1;
+            const int mj = (int)rec[(g & 1) * RB + lane];
+            const unsigned long long used = (unsigned long long)(unsigned char)rec[(g & 1) * RB + 64];
+            lds_sync<false>();
+            TRK_STAMP(3)
+            apply(mj, used, nd, c_box + (size_t)gl * dcap * 4, c_cls + (size_t)gl * dcap, c_conf + (size_t)gl * dcap, sg);
+        }
+    } else
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
         fl = (fl + 1 == FC) ? 0 : fl + 1;
@@ -182,6 +390,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
             // the chunk was fetched into registers while the previous one was being processed (one element per
             // thread: FC * dcap <= 512): hand it to LDS and start fetching the next one
             lds_sync<true>();
+            if (PIPE) cpar ^= 1, set_chunk(chunk + (size_t)cpar * chunk_sz);
             if (tid < FC) c_n[tid] = pf_n;
             if (tid < FC * dcap) {
                 reinterpret_cast<int4*>(c_box)[tid] = pf_box;
@@ -208,12 +417,13 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
             __builtin_amdgcn_s_waitcnt(0x0F70);
             lds_sync<MULTIWAVE || REPL>();
         }
+        TRK_STAMP(0)                                        // chunk hand-over
         int nd = c_n[fl];
-        nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
         const int* dbox = c_box + (size_t)fl * dcap * 4;        // [dcap][4]
         const int* dcls = c_cls + (size_t)fl * dcap;
         const double* dconf = c_conf + (size_t)fl * dcap;
         const double* darea = c_area + (size_t)fl * dcap;
+        nd = nd < 0 ? 0 : (nd > dcap ? dcap : nd);
         frame_count += 1;
         if (full) {
             if (row < dcap) sh.d2t[row] = -1;
@@ -282,7 +492,9 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                 xb[512 + wid] = (unsigned char)(pc ? (1u << wid) : 0u);
                 xb[520 + wid] = (unsigned char)winner;
             }
+            TRK_STAMP(1)                                    // own column tested and published
             lds_sync<true>();
+            TRK_STAMP(2)                                    // barrier
             auto orfold = [](unsigned long long x) {
                 unsigned t = (unsigned)x | (unsigned)(x >> 32);
                 t |= t >> 16;
@@ -436,142 +648,18 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
             }
         }
 
-        // ---- matched / missed (:182-211) ---------------------------------------------------------
-        if (active) {
-            if (matched_j >= 0) {
-                const int4 nb4 = *reinterpret_cast<const int4*>(dbox + matched_j * 4);
-                if (full) {
-                    const double ocx = (double)(r.x1 + r.x2) / 2.0, ocy = (double)(r.y1 + r.y2) / 2.0;
-                    const double ncx = (double)(nb4.x + nb4.z) / 2.0, ncy = (double)(nb4.y + nb4.w) / 2.0;
-                    r.conf = dconf[matched_j];
-                    r.age += 1, r.hits += 1;
-                    double4* h = reinterpret_cast<double4*>(hist + ((size_t)r.slot * L + r.hpos) * 4);
-                    *h = make_double4(ncx, ncy, ncx - ocx, ncy - ocy);
-                    r.vx = (float)(ncx - ocx), r.vy = (float)(ncy - ocy);
-                    r.hlen += 1;
-                    r.hpos = (r.hpos + 1 == L) ? 0 : r.hpos + 1;
-                    sh.d2t[matched_j] = r.id;
-                }
-                r.x1 = nb4.x, r.y1 = nb4.y, r.x2 = nb4.z, r.y2 = nb4.w;
-                r.misses = 0;
-            } else {
-                r.age += 1, r.misses += 1;
-            }
+        TRK_STAMP(3)                                        // association resolved
+        if (PIPE && wid == 0) {                             // the frame's decisions, for the trailing wave
+            rec[(f & 1) * RB + lane] = (signed char)matched_j;
+            if (lane == 0) rec[(f & 1) * RB + 64] = (signed char)(unsigned char)used;
         }
-
-        // ---- births (:214-225) ------------------------------------------------------------------
-        const unsigned long long dmask = nd >= 64 ? ~0ull : ((1ull << nd) - 1ull);
-        const unsigned long long unm = ~used & dmask;
-        const int nb = __popcll(unm);
-        int nb_fit = nb;
-        if (T + nb > tcap) nb_fit = tcap - T, status |= 1;
-        if (nb > 0 && !full) {
-            // light copy: the new rows' boxes only
-            if (row >= T && row < T + nb_fit) {
-                const int4 b4 = *reinterpret_cast<const int4*>(dbox + nth_set_bit(unm, row - T) * 4);
-                r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
-                r.misses = 0;
-            }
-            T += nb_fit;
-        } else if (nb > 0) {
-            // rank of each free history slot; the b-th birth takes the b-th free slot
-            {
-                const unsigned word = sh.slot_bits[row >> 5];
-                const bool is_free = !((word >> (row & 31)) & 1u);
-                int below = __popc(~word & ((1u << (row & 31)) - 1u));
-                for (int w = 0; w < (row >> 5); ++w) below += 32 - __popc(sh.slot_bits[w]);
-                if (is_free && below < nb_fit) sh.birth_slot[below] = row;
-            }
-            if (row < nd && ((unm >> row) & 1ull)) {
-                const int b = __popcll(unm & ((1ull << row) - 1ull));
-                sh.d2t[row] = next_id + b;
-            }
-            lds_sync<MULTIWAVE>();
-            if (row >= T && row < T + nb_fit) {
-                const int b = row - T;
-                const int j = nth_set_bit(unm, b);
-                r.id = next_id + b;
-                r.x1 = dbox[j * 4 + 0], r.y1 = dbox[j * 4 + 1], r.x2 = dbox[j * 4 + 2], r.y2 = dbox[j * 4 + 3];
-                r.cls = dcls[j];
-                r.conf = dconf[j];
-                r.age = 0, r.hits = 1, r.misses = 0;
-                r.slot = sh.birth_slot[b];
-                r.hlen = 1;
-                r.hpos = (L == 1) ? 0 : 1;
-                r.vx = 0.f, r.vy = 0.f;
-                double4* h = reinterpret_cast<double4*>(hist + (size_t)r.slot * L * 4);
-                *h = make_double4((double)(r.x1 + r.x2) / 2.0, (double)(r.y1 + r.y2) / 2.0, 0.0, 0.0);
-                atomicOr(&sh.slot_bits[r.slot >> 5], 1u << (r.slot & 31));
-            }
-            next_id += nb;
-            T += nb_fit;
-        }
-
-        // ---- deaths (:228-233): order-preserving compaction --------------------------------------
-        const bool live_row = row < T;
-        const bool dead = live_row && (r.misses > cfg.max_age);
-        int any_dead;
-        if (MULTIWAVE) {
-            if (row == 0) sh.misc[0] = 0;
-            lds_sync<MULTIWAVE>();
-            if (dead) sh.misc[0] = 1;
-            lds_sync<MULTIWAVE>();
-            any_dead = sh.misc[0];
-        } else {
-            any_dead = __ballot(dead) != 0ull;
-        }
-        if (any_dead) {
-            const bool keep = live_row && !dead;
-            const unsigned long long kb = __ballot(keep);
-            int pos = __popcll(kb & ((1ull << lane) - 1ull));
-            int total = __popcll(kb);
-            if (MULTIWAVE) {
-                if (lane == 0) sh.w_cnt[wid] = total;
-                lds_sync<MULTIWAVE>();
-                total = 0;
-                for (int w = 0; w < nwaves; ++w) {
-                    if (w < wid) pos += sh.w_cnt[w];
-                    total += sh.w_cnt[w];
-                }
-            }
-            if (!full) {
-                // light copy: boxes and miss counters move down the same way
-                int* ls = reinterpret_cast<int*>(stage);
-                if (keep) {
-                    *reinterpret_cast<int4*>(ls + pos * 8) = make_int4(r.x1, r.y1, r.x2, r.y2);
-                    ls[pos * 8 + 4] = r.misses;
-                }
-                lds_sync<MULTIWAVE>();
-                T = total;
-                if (row < T) {
-                    const int4 b4 = *reinterpret_cast<const int4*>(ls + row * 8);
-                    r.x1 = b4.x, r.y1 = b4.y, r.x2 = b4.z, r.y2 = b4.w;
-                    r.misses = ls[row * 8 + 4];
-                }
-            } else {
-                if (dead) atomicAnd(&sh.slot_bits[r.slot >> 5], ~(1u << (r.slot & 31)));
-                if (keep) {
-                    av_track_row g;
-                    g.id = r.id, g.x1 = r.x1, g.y1 = r.y1, g.x2 = r.x2, g.y2 = r.y2, g.cls = r.cls;
-                    g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
-                    g.flags = r.hpos, g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;      // flags carries hpos through the staging only
-                    stage[pos] = g;
-                }
-                lds_sync<MULTIWAVE>();
-                T = total;
-                if (row < T) {
-                    const av_track_row g = stage[row];
-                    r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
-                    r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
-                    r.hpos = g.flags;
-                    r.conf = g.conf, r.vx = g.vx, r.vy = g.vy;
-                }
-            }
-        }
-
-        // ---- per-frame outputs --------------------------------------------------------------------
-        if (full) emit(sf);
-        lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
+        apply(matched_j, used, nd, dbox, dcls, dconf, sf);
+    }
+    if (PIPE && wid < REP) lds_sync<true>();               // the closing barrier: the last frame's decisions are published
+#undef TRK_STAMP
+    if (TIMED && s == 0 && lane == 0 && det2trk) {
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int k = 0; k < 8; ++k) det2trk[wid * 8 + k] = (int)tacc[k];
     }
 
     // ---- persist ----------------------------------------------------------------------------------
@@ -587,15 +675,15 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
     if (row == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
 }
 
-template <bool MULTIWAVE, int DREG, int REP>
+template <bool MULTIWAVE, int DREG, int REP, bool TIMED = false, int PIPE = 0>
 __global__ void __launch_bounds__(1024) tracker_kernel(av_tracker_cfg cfg, int n_frames, int dcap, const int32_t* __restrict__ det_n,
                                const int32_t* __restrict__ det_box, const int32_t* __restrict__ det_cls,
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
-                               int32_t* __restrict__ det2trk, int chunk_frames) {
+                               int32_t* __restrict__ det2trk, int chunk_frames, unsigned long long wave_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    tracker_body<MULTIWAVE, DREG, REP>(cfg, n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, state_all, snap, snap_n, det2trk,
-                                       chunk_frames, blockIdx.x, smem);
+    tracker_body<MULTIWAVE, DREG, REP, TIMED, PIPE>(cfg, n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, state_all, snap, snap_n,
+                                              det2trk, chunk_frames, blockIdx.x, smem, wave_map);
 }
 
 __global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, unsigned char* state) {
@@ -604,6 +692,28 @@ __global__ void tracker_reset_kernel(int n_streams, size_t bytes_per_stream, uns
     int* hdr = reinterpret_cast<int*>(state + (size_t)s * bytes_per_stream);
     for (int i = 0; i < HDR_INTS; ++i) hdr[i] = 0;
     hdr[1] = 1;     // next_id starts at 1 (multi_object_tracker.py:81)
+}
+
+// the windowed replica kernel (eight column waves, + the trailing wave with PIPE); more than 64 KB of dynamic LDS needs the attribute
+template <bool TIMED, int PIPE>
+int launch_replicas(int n_streams, size_t lds, hipStream_t st, const av_tracker_cfg& cfg, int n_frames, int dcap, const int32_t* det_n,
+                    const int32_t* det_box, const int32_t* det_cls, const double* det_conf, int tcap, unsigned char* state,
+                    av_track_row* snap, int32_t* snap_n, int32_t* det2trk, int fc) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tracker_kernel<false, 8, 8, TIMED, PIPE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // hardware wave -> role.  SIMD of hardware wave h = h % 4.  With the trailing wave: SIMD 0 = column 0 + columns 6, 7; SIMD 1 = the
+    // trailing wave + column 3; SIMD 2 = columns 1, 4; SIMD 3 = columns 2, 5 (0.268 -> 0.260 ms per 64 x 256 frames).
+    // AVHOT_TRACKER_MAP=0: identity
+    const char* map_env = getenv("AVHOT_TRACKER_MAP");
+    unsigned long long wave_map = PIPE == 1 ? 0x754362180ull : 0xFEDCBA9876543210ull;
+    if (map_env && atoi(map_env) == 0) wave_map = 0xFEDCBA9876543210ull;
+    hipLaunchKernelGGL((tracker_kernel<false, 8, 8, TIMED, PIPE>), dim3(n_streams), dim3(64 * (8 + PIPE)), lds, st, cfg, n_frames,
+                       dcap, det_n, det_box, det_cls, det_conf, tcap, state, snap, snap_n, det2trk, fc, wave_map);
+    return AV_OK;
 }
 
 }  // namespace
@@ -656,27 +766,30 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
 #define AV_TRK_LAUNCH(MW, DR, RP)                                                                                  \
     hipLaunchKernelGGL((tracker_kernel<MW, DR, RP>), dim3(n_streams), dim3(tcap * RP), lds, as_stream(stream), *cfg,   \
                        n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, \
-                       det2trk, fc)
+                       det2trk, fc, 0xFEDCBA9876543210ull)
     if (rep) {
         // A window of frames is a long per-stream latency chain on one CU per stream; whatever else lands on that CU competes
         // with it for issue slots and for the CU's memory pipeline.  In the batched step the HBM-bound planner runs on the
         // other stream: claiming (almost) the whole LDS keeps its workgroups (38 KB each) off the tracker's 64 CUs -- config 4
         // 0.380 -> 0.352 ms per step (100 KB: no change, two planner workgroups still fit; 125 / 150 KB: 0.357 / 0.352).
         // AVHOT_TRACKER_LDS_KB overrides (0 = only what the kernel needs).
+        // Windows also get the trailing ninth wave (PIPE, see tracker_body); AVHOT_TRACKER_PIPE=0 / 1 overrides.
         const char* pad_env = getenv("AVHOT_TRACKER_LDS_KB");
+        const char* pipe_env = getenv("AVHOT_TRACKER_PIPE");
+        const int pipe = pipe_env ? (atoi(pipe_env) != 0 ? 1 : 0) : (n_frames >= 16 ? 1 : 0);
+        const bool timed = getenv("AVHOT_TRACKER_TIMED") != nullptr;
         const size_t want = pad_env ? (size_t)atoi(pad_env) * 1024 : (n_frames >= 16 ? (size_t)150 * 1024 : 0);
-        const size_t lds_need = lds;
-        if (want > lds_need && want <= 160 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tracker_kernel<false, 8, REPW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL((tracker_kernel<false, 8, REPW>), dim3(n_streams), dim3(tcap * REPW), want, as_stream(stream), *cfg,
-                               n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, (unsigned char*)state, snap, snap_n, det2trk, fc);
-        } else
-        AV_TRK_LAUNCH(false, 8, REPW);
+        const size_t lds_need = pipe ? rep_bytes * (REPW + pipe) + 2 * chunk_bytes + 2 * 576 + 2 * 80 + 16 : lds;
+        AV_REQUIRE(lds_need <= 160 * 1024, AV_EINVAL, "av_tracker_update: %zu bytes of LDS", lds_need);
+        const size_t lds_use = want > lds_need && want <= 160 * 1024 ? want : lds_need;
+        int rc;
+#define AV_TRK_REP(TM, PP)                                                                                                            \
+    launch_replicas<TM, PP>(n_streams, lds_use, as_stream(stream), *cfg, n_frames, dcap, det_n, det_box, det_cls, det_conf, tcap, \
+                            (unsigned char*)state, snap, snap_n, det2trk, fc)
+        if (pipe == 1) rc = timed ? AV_TRK_REP(true, 1) : AV_TRK_REP(false, 1);
+        else rc = timed ? AV_TRK_REP(true, 0) : AV_TRK_REP(false, 0);
+#undef AV_TRK_REP
+        if (rc != AV_OK) return rc;
     } else if (tcap == 64) {
         if (dcap <= 8) AV_TRK_LAUNCH(false, 8, 1);
         else if (dcap <= 16) AV_TRK_LAUNCH(false, 16, 1);
