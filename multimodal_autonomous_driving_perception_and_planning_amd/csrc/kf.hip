@@ -365,8 +365,10 @@ __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames,
     for (int f0 = 0; f0 < n_frames; f0 += KF_BATCH) {
         const int nb = (n_frames - f0) < KF_BATCH ? (n_frames - f0) : KF_BATCH;
         const size_t sf0 = (size_t)s * n_frames + f0;
+        int m_mine = 0;
         if (lane < nb) {
             const int m = mode ? (int)mode[sf0 + lane] : 1;
+            m_mine = m;
             ml[lane] = m;
             double4 zz = make_double4(0.0, 0.0, 0.0, 0.0);
             if (z && (m == 1 || m == 3)) zz = reinterpret_cast<const double4*>(z)[sf0 + lane];
@@ -377,25 +379,42 @@ __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
+        const unsigned long long ones = __ballot(m_mine == 1);   // frames of the batch that predict + update (scalar test in the loop)
         // ---- sequential recursion (lanes 0 and 1 carry the two axes) --------------------------------
-        for (int fb = 0; fb < nb; ++fb) {
-            const int m = ml[fb];
-            const double zp = zl[fb][ax], zv = zl[fb][2 + ax];
-            double vpred = a.x1;
-            if (steady && m == 1) {
+        for (int fb = 0; fb < nb;) {
+            if (steady) {
                 // The covariance recursion does not see the measurements.  Once a predict+update frame has
                 // reproduced the previous posterior P bit for bit, every further predict+update frame computes
                 // the same prior, gain and posterior again: only the state moves (same expressions as below).
-                const double nx0 = a.x0 + dt * a.x1 + h * a.x2;
-                const double nx1 = a.x1 + dt * a.x2;
-                a.x0 = nx0, a.x1 = nx1;
-                time += dt;
-                vpred = a.x1;
-                const double y0 = zp - a.x0, y1 = zv - a.x1;
-                a.x0 = a.x0 + (Kc[0][0] * y0 + Kc[0][1] * y1);
-                a.x1 = a.x1 + (Kc[1][0] * y0 + Kc[1][1] * y1);
-                a.x2 = a.x2 + (Kc[2][0] * y0 + Kc[2][1] * y1);
-            } else {
+                // A loop of its own: the only values it carries from frame to frame are the state and the clock (inside
+                // the general loop the compiler moved the whole filter, ~40 register pairs, around the back edge on every frame:
+                // 935 cycles per frame, of which the arithmetic was a quarter).
+                const double p00 = a.p[0][0], p11 = a.p[1][1];
+                while (fb < nb && ((ones >> fb) & 1ull)) {
+                    const double zp = zl[fb][ax], zv = zl[fb][2 + ax];
+                    const double nx0 = a.x0 + dt * a.x1 + h * a.x2;
+                    const double nx1 = a.x1 + dt * a.x2;
+                    a.x0 = nx0, a.x1 = nx1;
+                    time += dt;
+                    const double vpred = a.x1;
+                    const double y0 = zp - a.x0, y1 = zv - a.x1;
+                    a.x0 = a.x0 + (Kc[0][0] * y0 + Kc[0][1] * y1);
+                    a.x1 = a.x1 + (Kc[1][0] * y0 + Kc[1][1] * y1);
+                    a.x2 = a.x2 + (Kc[2][0] * y0 + Kc[2][1] * y1);
+                    if (lane < 2) {
+                        double* w = raw[fb];
+                        w[ax] = a.x0, w[2 + ax] = a.x1, w[4 + ax] = vpred;
+                        w[6 + ax] = p00, w[8 + ax] = p11;
+                        if (lane == 0) w[10] = time, w[11] = 1.0;
+                    }
+                    ++fb;
+                }
+                if (fb >= nb) break;
+            }
+            const int m = ml[fb];
+            const double zp = zl[fb][ax], zv = zl[fb][2 + ax];
+            double vpred = a.x1;
+            {
                 if (m != 3) {
                     axis_predict(a, dt, h, q);
                     time += dt;
@@ -415,6 +434,7 @@ __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames,
                 w[6 + ax] = a.p[0][0], w[8 + ax] = a.p[1][1];
                 if (lane == 0) w[10] = time, w[11] = (double)m;
             }
+            ++fb;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
