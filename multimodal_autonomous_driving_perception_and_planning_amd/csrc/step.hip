@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
         const int s = blockIdx.x - a.S;
         if (tid < 64) {
             const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid);
-            if (!separable && tid == 0) kf_dense_stream(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);
+            if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);   // (LDS form: kf_dense.inc)
         }
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
         plan_block<1, STEP_NW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
