@@ -327,11 +327,16 @@ __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames,
     return true;
 }
 
+// DENSE: a stream that turns out not to be separable is finished here, by lane 0 with the dense filter's LDS form (kf_dense.inc),
+// instead of by a second launch of kf_kernel -- the frame-by-frame calls (one or two frames per launch), where that second launch
+// was 5 us of every call.  Windows keep the register form in its own launch.
+template <bool DENSE>
 __global__ void __launch_bounds__(64) kf_axis_kernel(av_kf_cfg cfg, int n_frames, const double* __restrict__ z,
                                                      const uint8_t* __restrict__ mode, double* __restrict__ kf_state,
                                                      double* __restrict__ out_state, double* __restrict__ plan_state) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of throughput kernels on the same SIMD
-    kf_axis_body(cfg, n_frames, z, mode, kf_state, out_state, plan_state, blockIdx.x, threadIdx.x);
+    const bool separable = kf_axis_body(cfg, n_frames, z, mode, kf_state, out_state, plan_state, blockIdx.x, threadIdx.x);
+    if (DENSE && !separable && threadIdx.x == 0) kf_dense_stream_lds(cfg, blockIdx.x, n_frames, z, mode, kf_state, out_state, plan_state);
 }
 
 __global__ void kf_reset_kernel(int n_streams, double* kf_state) {
@@ -361,7 +366,13 @@ int av_kf_step(av_ctx* ctx, av_stream_t stream, const av_kf_cfg* cfg, int n_stre
     AV_REQUIRE(z || mode, AV_EINVAL, "av_kf_step: z may only be NULL when every mode is 0 or 2");
     AV_REQUIRE(n_streams > 0 && n_frames > 0, AV_EINVAL, "av_kf_step: n_streams/n_frames must be > 0");
     // separable streams: one wave each (kf_axis_kernel); the rest (flagged in kf_state[45]): dense kernel
-    hipLaunchKernelGGL(kf_axis_kernel, dim3(n_streams), dim3(64), 0, as_stream(stream), *cfg, n_frames, z, mode,
+    if (n_frames <= 2) {
+        hipLaunchKernelGGL(kf_axis_kernel<true>, dim3(n_streams), dim3(64), 0, as_stream(stream), *cfg, n_frames, z, mode, kf_state,
+                           out_state, plan_state);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
+    hipLaunchKernelGGL(kf_axis_kernel<false>, dim3(n_streams), dim3(64), 0, as_stream(stream), *cfg, n_frames, z, mode,
                        kf_state, out_state, plan_state);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(kf_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, as_stream(stream), *cfg, n_streams,

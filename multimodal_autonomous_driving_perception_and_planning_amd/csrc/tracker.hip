@@ -772,13 +772,15 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
         // with it for issue slots and for the CU's memory pipeline.  In the batched step the HBM-bound planner runs on the
         // other stream: claiming (almost) the whole LDS keeps its workgroups (38 KB each) off the tracker's 64 CUs -- config 4
         // 0.380 -> 0.352 ms per step (100 KB: no change, two planner workgroups still fit; 125 / 150 KB: 0.357 / 0.352).
+        // 156 KB also keeps the Kalman kernel's one-wave workgroups (8.4 KB of LDS each) off these CUs: 0.306-0.310 against
+        // 0.310-0.313 ms per step.
         // AVHOT_TRACKER_LDS_KB overrides (0 = only what the kernel needs).
         // Windows also get the trailing ninth wave (PIPE, see tracker_body); AVHOT_TRACKER_PIPE=0 / 1 overrides.
         const char* pad_env = getenv("AVHOT_TRACKER_LDS_KB");
         const char* pipe_env = getenv("AVHOT_TRACKER_PIPE");
         const int pipe = pipe_env ? (atoi(pipe_env) != 0 ? 1 : 0) : (n_frames >= 16 ? 1 : 0);
         const bool timed = getenv("AVHOT_TRACKER_TIMED") != nullptr;
-        const size_t want = pad_env ? (size_t)atoi(pad_env) * 1024 : (n_frames >= 16 ? (size_t)150 * 1024 : 0);
+        const size_t want = pad_env ? (size_t)atoi(pad_env) * 1024 : (n_frames >= 16 ? (size_t)156 * 1024 : 0);
         const size_t lds_need = pipe ? rep_bytes * (REPW + pipe) + 2 * chunk_bytes + 2 * 576 + 2 * 80 + 16 : lds;
         AV_REQUIRE(lds_need <= 160 * 1024, AV_EINVAL, "av_tracker_update: %zu bytes of LDS", lds_need);
         const size_t lds_use = want > lds_need && want <= 160 * 1024 ? want : lds_need;
