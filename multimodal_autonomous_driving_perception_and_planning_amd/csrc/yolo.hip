@@ -173,6 +173,112 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     }
 }
 
+// GEMM form for the long-K 3x3 layers on small maps (cin = 128, stride 2: P4 -> P5 in the backbone and in the neck; K = 1152).
+// conv_mfma_kernel gives every wave its own 147-KB stream of weights from L2 for 32 pixels (5.5 % MFMA busy, 52.6 / 41.6 + 29.1 us
+// per 64 frames); here a workgroup of four waves owns 64 flattened output pixels x 128 output channels and walks K half a TAP (64
+// input channels: two 32-wide MFMA steps, 16 MFMAs per wave) per barrier through double-buffered LDS slabs (weights 128 rows x
+// 128 B, pixels 64 rows x 128 B, 160-byte rows = 32 mod 64: conflict-free ds_read_b128; 60 KB: two workgroups per CU cover each
+// other's waits).  A step's six 16-byte pieces per thread are requested at the top of the step before the previous one (ahead of
+// that step's MFMAs) and go to LDS at the top of the previous step, behind its barrier.  22.0 + 18.2 us per 64 frames.
+// Two earlier forms, for the record: 32 channels per barrier with a three-deep register ring -- the compiler reused the ring's
+// registers as address temporaries and waited for every load right behind its issue (28-35 us per layer); a whole tap per barrier
+// (110 KB of LDS, one workgroup per CU, 32.8 + 19.4 us).  A select on a loaded value (`ok ? v : 0`) placed at the load makes the
+// compiler wait for ALL loads there (vmcnt(0)): out-of-image pieces are zeroed when they go to LDS instead.
+// Same K order (tap outer, 32-channel chunk inner), same zero padding, same epilogue as conv_mfma_kernel: bit-identical outputs
+// (tests/test_gpu_yolo.py::test_gemm_form_stride2_layers_equal_streaming_kernel).
+constexpr int CG_CIN = 128, CG_SC = 64, CG_ROWB = CG_SC * 2 + 32;     // input channels; channels per barrier step (half a tap: 60 KB of LDS,
+                                                                       // two workgroups per CU cover each other's load latency); bytes per LDS row
+__global__ void __launch_bounds__(256) conv_gemm128_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+    unsigned char* As = cg_smem;                              // [2][128 rows]
+    unsigned char* Bs = cg_smem + 2 * 128 * CG_ROWB;          // [2][64 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;       // this wave's 64 output channels / 32 pixels of the workgroup's 128 x 64
+    const int pix_base = blockIdx.x * 64, ch_base = blockIdx.y * 128;
+    // ---- what this thread stages per step: 64 bytes of one weight row and 32 bytes of one pixel's channels ------------------------
+    const int arow_s = tid >> 1, ahalf = tid & 1, brow_s = tid >> 2, bq = tid & 3;
+    const half_t* wsrc = a.wgt + (size_t)(ch_base + arow_s) * a.kpad + ahalf * 32;
+    const int sp = pix_base + brow_s;
+    const bool spv = sp < a.npix;
+    const int spp = spv ? sp : 0;
+    const int sn = spp / (a.Ho * a.Wo), sr = spp - sn * a.Ho * a.Wo, soy = sr / a.Wo, sox = sr - soy * a.Wo;
+    const int iy0 = soy * a.stride - 1, ix0 = sox * a.stride - 1;
+    // (twelve named registers, not arrays: as arrays written in one lambda and read in another they ended up in scratch)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1;
+    unsigned rm = 0;
+    constexpr int SPT = CG_CIN / CG_SC, NSTEP = 9 * SPT;      // steps per tap, steps
+    auto gload = [&](int st) {
+        const int tap = st / SPT, part = st - tap * SPT, ky = tap / 3, kx = tap - ky * 3;
+        const uint4* wp = reinterpret_cast<const uint4*>(wsrc + (size_t)st * CG_SC);
+        ra0 = wp[0], ra1 = wp[1], ra2 = wp[2], ra3 = wp[3];
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = spv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        // (clamped to pixel (0, 0) when outside: always readable; zeroed when the pieces go to LDS)
+        const uint4* bp = reinterpret_cast<const uint4*>(a.in + ((size_t)(sn * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.in_cs + a.in_coff +
+                                                         part * CG_SC + bq * 16);
+        rb0 = bp[0], rb1 = bp[1];
+        rm = ok ? ~0u : 0u;
+    };
+    auto msk = [&](const uint4& v) { return make_uint4(v.x & rm, v.y & rm, v.z & rm, v.w & rm); };
+    auto lstore = [&](int buf) {
+        uint4* da = reinterpret_cast<uint4*>(As + (size_t)(buf * 128 + arow_s) * CG_ROWB + ahalf * 64);
+        da[0] = ra0, da[1] = ra1, da[2] = ra2, da[3] = ra3;
+        uint4* db = reinterpret_cast<uint4*>(Bs + (size_t)(buf * 64 + brow_s) * CG_ROWB + bq * 32);
+        db[0] = msk(rb0), db[1] = msk(rb1);
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bsv[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch_base + wm * 64 + mt * 16 + 4 * h);
+    gload(0);
+    lstore(0);
+    gload(1);
+#pragma unroll 1
+    for (int tap = 0; tap < NSTEP; ++tap) {        // (`tap` counts steps: half taps)
+        __syncthreads();                           // the step's slab is in LDS; the other buffer's readers (step - 1) are done
+        const unsigned char* arow = As + (size_t)((tap & 1) * 128 + wm * 64 + l15) * CG_ROWB + 16 * h;
+        const unsigned char* brow = Bs + (size_t)((tap & 1) * 64 + wn * 32 + l15) * CG_ROWB + 16 * h;
+        if (tap + 1 < NSTEP) lstore((tap + 1) & 1);  // requested a whole step ago
+        if (tap + 2 < NSTEP) gload(tap + 2);         // in flight during this step's MFMAs; goes to LDS at the top of the next step
+#pragma unroll
+        for (int c = 0; c < CG_SC / 32; ++c) {
+            half8 A[4], B[2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) A[mt] = *reinterpret_cast<const half8*>(arow + mt * 16 * CG_ROWB + c * 64);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) B[nt] = *reinterpret_cast<const half8*>(brow + nt * 16 * CG_ROWB + c * 64);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(bsv[mt].x), "v"(bsv[mt].y), "v"(bsv[mt].z), "v"(bsv[mt].w));
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int ch = ch_base + wm * 64 + mt * 16 + 4 * h;
+        const float4 bs = bsv[mt];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int pi = pix_base + wn * 32 + nt * 16 + l15;
+            if (pi >= a.npix) continue;
+            const size_t p = (size_t)pi;
+            float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
+            if (a.act)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+            if (a.out32) *reinterpret_cast<float4*>(a.out32 + p * a.out_cs + a.out_coff + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // LDS-tiled variant for Cin % 32 == 0 (all but the first few layers).  A workgroup (4 waves) owns an 8x16
 // output tile of one image and 16*MT output channels.  Per 32-channel chunk of the input it stages
 //   patch [PH*PW pixels][32 ch]   (the tile's receptive field incl. halo, zero outside the image)
@@ -2125,6 +2231,12 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
             AV_LAUNCH_CHECK();
             return AV_OK;
         }
+        if (a.ksz == 3 && a.stride == 2 && a.cin == CG_CIN && a.cout % 128 == 0 && !a.res && a.kreal == 9 * a.cin &&
+            !force_direct && !getenv("AVHOT_CONV_NO_GEMM")) {
+            hipLaunchKernelGGL(conv_gemm128_kernel, dim3((a.npix + 63) / 64, a.cout / 128), dim3(256), (size_t)2 * (128 + 64) * CG_ROWB, st, a);
+            AV_LAUNCH_CHECK();
+            return AV_OK;
+        }
         constexpr int NT = 2;
         const dim3 grid((a.npix + 16 * NT * 4 - 1) / (16 * NT * 4), a.cout / (16 * op.mt));
         if (op.mt == 4) hipLaunchKernelGGL((conv_mfma_kernel<4, NT>), grid, dim3(256), 0, st, a);
@@ -2257,7 +2369,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
          dev_alloc(y, (void**)&y.sidx, (size_t)batch * y.A * 4) && dev_alloc(y, (void**)&y.scount, (size_t)batch * 4);
     y.named = {{0, Slice{x0, 0, 3}}, {1, Slice{b1, 0, 32}}, {2, Slice{b2, 0, 32}}, {4, Slice{cat14, 128, 64}},
                {6, Slice{cat11, 256, 128}}, {8, Slice{b8, 0, 256}}, {9, Slice{cat20, 128, 256}}, {12, Slice{cat17, 64, 128}},
-               {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}};
+               {15, Slice{p3, 0, 64}}, {18, Slice{p4, 0, 128}}, {21, Slice{p5, 0, 256}}, {7, Slice{b7, 0, 256}}, {19, Slice{cat20, 0, 128}}};
     if (y.dbg_cat >= 0) y.named.push_back({40, Slice{y.dbg_cat, 0, y.bufs[y.dbg_cat].C}});
     y.wsrc = nullptr;
     if (!ok) {
@@ -2293,6 +2405,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<2, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 64, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AV_WS_ATTR1(MTV, NTV, NWV, CP) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))

@@ -454,3 +454,33 @@ def test_two_to_one_preprocess_equals_generic_kernel(setup, monkeypatch):
     other.detect(frame)
     assert np.array_equal(other.tensor(0), fast)
     other.close()
+
+
+def test_gemm_form_stride2_layers_equal_streaming_kernel(setup, monkeypatch):
+    """The two cin = 128 stride-2 convolutions (layer 7: 128 -> 256 into P5; layer 19: 128 -> 128 in the neck) run as an LDS-tiled
+    GEMM over flattened output pixels (conv_gemm128_kernel); AVHOT_CONV_NO_GEMM (read per launch) sends them through
+    conv_mfma_kernel, whose K order, padding and epilogue are the same: their outputs and the detections must be the same bits
+    (a batch whose 240-pixel maps do not fill the last 128-pixel tile: 5 images = 1200 pixels)."""
+    import torch
+    Y, R, frame, feats, model, _ = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame, synthetic_frame(720, 1280, 6, 40), np.full((720, 1280, 3), 200, np.uint8), synthetic_frame(720, 1280, 2, 77),
+              np.random.RandomState(5).randint(0, 256, (720, 1280, 3)).astype(np.uint8)]
+    m = Y.YoloV8n("random:0", batch=len(frames))
+    m._prepare(720, 1280)
+    m._frames.copy_(torch.as_tensor(np.stack(frames)))
+
+    def run():
+        m.forward_device(m._frames)
+        torch.cuda.synchronize()
+        return (m.tensor(7, image=None).copy(), m.tensor(19, image=None).copy(), m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(),
+                m._conf.cpu().numpy().copy())
+    gemm = run()
+    monkeypatch.setenv("AVHOT_CONV_NO_GEMM", "1")
+    stream = run()
+    monkeypatch.delenv("AVHOT_CONV_NO_GEMM")
+    assert gemm[0].shape == (len(frames), 12, 20, 256) and gemm[0].any() and gemm[1].shape == (len(frames), 12, 20, 128) and gemm[1].any()
+    for k in range(2):
+        assert np.array_equal(gemm[k].view(np.uint32), stream[k].view(np.uint32)), (k, int((gemm[k] != stream[k]).sum()))
+    assert np.array_equal(gemm[2], stream[2]) and np.array_equal(gemm[3], stream[3]) and np.array_equal(gemm[4], stream[4])
+    m.close()
