@@ -484,3 +484,32 @@ def test_gemm_form_stride2_layers_equal_streaming_kernel(setup, monkeypatch):
         assert np.array_equal(gemm[k].view(np.uint32), stream[k].view(np.uint32)), (k, int((gemm[k] != stream[k]).sum()))
     assert np.array_equal(gemm[2], stream[2]) and np.array_equal(gemm[3], stream[3]) and np.array_equal(gemm[4], stream[4])
     m.close()
+
+
+def test_gemm_form_1x1_layers_equal_weight_stationary_kernels(setup, monkeypatch):
+    """conv_gemm128_kernel also takes the 1 x 1 convolutions with cin a multiple of 64 and cout of 128 (cv1 / cv2 of the P4 / P5 blocks,
+    SPPF); AVHOT_CONV_NO_GEMM_1X1 (read per launch) sends them through conv1x1_ws_kernel / conv_lds_kernel instead -- same chunk
+    order, same epilogue.  The outputs of the blocks they sit in (layers 6, 8, 9, 12, 18, 21) and the detections must be the same bits."""
+    import torch
+    Y, R, frame, feats, model, _ = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame, synthetic_frame(720, 1280, 6, 40), np.full((720, 1280, 3), 200, np.uint8), synthetic_frame(720, 1280, 2, 77),
+              np.random.RandomState(5).randint(0, 256, (720, 1280, 3)).astype(np.uint8)]
+    m = Y.YoloV8n("random:0", batch=len(frames))
+    m._prepare(720, 1280)
+    m._frames.copy_(torch.as_tensor(np.stack(frames)))
+
+    def run():
+        m.forward_device(m._frames)
+        torch.cuda.synchronize()
+        return [m.tensor(t, image=None).copy() for t in (6, 8, 9, 12, 18, 21)] + [m._n.cpu().numpy().copy(), m._box.cpu().numpy().copy(),
+                                                                                 m._conf.cpu().numpy().copy()]
+    gemm = run()
+    monkeypatch.setenv("AVHOT_CONV_NO_GEMM_1X1", "1")
+    base = run()
+    monkeypatch.delenv("AVHOT_CONV_NO_GEMM_1X1")
+    for k in range(6):
+        assert base[k].any() and np.array_equal(base[k].view(np.uint32), gemm[k].view(np.uint32)), (k, int((base[k] != gemm[k]).sum()))
+    for k in range(6, 9):
+        assert np.array_equal(base[k], gemm[k])
+    m.close()
