@@ -4,12 +4,19 @@
 # Output: gpurun_out/<tag>/<name>/*_results.db (rocpd SQLite) -> tools/profiles_from_db.py turns them into profiles/*.csv / *.json
 set -e
 TAG=${1:-r03}
-ONLY=${2:-all}          # "hot": only the config-4 / config-2 traces and the tracker counters (after a change to tracker / kf / step only)
+ONLY=${2:-all}          # "hot": only the config-4 / config-2 traces and the tracker counters (after a change to tracker / kf / step only);
+                        # "yolo": only the detector's traces and MFMA counters + the config-3 trace (after a change to yolo.hip only)
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 trace() { name=$1; shift; rocprofv3 --kernel-trace -d $OUT/$name -o t -- "$@" > $OUT/$name.log 2>&1; echo "trace $name done"; }
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr -d $OUT/$name -o p -- "$@" > $OUT/$name.log 2>&1; echo "pmc $name done"; }
+if [ "$ONLY" = yolo ]; then
+  trace bench_config3 python3 bench.py --no-also --no-cpu-baseline --workload config3
+  trace yolo_b64 python3 tools/ybench.py --batch 64 --reps 5
+  pmc yolo_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python3 tools/ybench.py --batch 64 --reps 3
+  ls $OUT; exit 0
+fi
 trace bench_config4 python3 bench.py --no-also --no-cpu-baseline
 trace bench_config2 python3 bench.py --no-also --no-cpu-baseline --workload config2 --steps 4 --warmup 1 --window 32768
 trace bench_config4_w1 python3 bench.py --no-also --no-cpu-baseline --workload config4 --window 1 --steps 500 --warmup 50
