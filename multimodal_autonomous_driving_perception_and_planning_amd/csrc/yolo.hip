@@ -216,8 +216,13 @@ __global__ void __launch_bounds__(256) conv_gemm128_kernel(ConvArgs a) {
         const int iy = iy0 + ky, ix = ix0 + kx;
         const bool ok = spv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         // (clamped to pixel (0, 0) when outside: always readable; zeroed when the pieces go to LDS)
-        const uint4* bp = reinterpret_cast<const uint4*>(a.in + ((size_t)(sn * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.in_cs + a.in_coff +
-                                                         part * CG_SC + bq * 16);
+        const int cy = ok ? iy : 0, cx = ok ? ix : 0, c0 = part * CG_SC + bq * 16;
+        const half_t* src = a.in + ((size_t)(sn * a.H + cy) * a.W + cx) * a.in_cs + a.in_coff + c0;
+        if (a.in2) {     // virtual Upsample + Concat (1 x 1 only; k1 a multiple of 64): channels below k1 from `in` at half resolution
+            if (part * CG_SC >= a.k1) src = a.in2 + ((size_t)(sn * a.H + cy) * a.W + cx) * a.in2_cs + a.in2_coff + c0 - a.k1;
+            else src = a.in + ((size_t)(sn * (a.H >> 1) + (cy >> 1)) * (a.W >> 1) + (cx >> 1)) * a.in_cs + a.in_coff + c0;
+        }
+        const uint4* bp = reinterpret_cast<const uint4*>(src);
         rb0 = bp[0], rb1 = bp[1];
         rm = ok ? ~0u : 0u;
     };
@@ -2553,6 +2558,11 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                 v.in2 = c.in, v.in2_cs = c.in_cs, v.in2_coff = c.in_coff + op.C, v.k1 = op.C;   // channels [k1, cin): the concat buffer's own part
                 const int tiles_x = (v.Wo + LT_W - 1) / LT_W, tiles_y = (v.Ho + LT_H - 1) / LT_H;
                 const size_t lds = (((size_t)LT_H * LT_W * LT_PIXB + 15) & ~size_t(15)) + (size_t)64 * (LT_CK * 2 + 32);
+                if (v.cin % CG_SC == 0 && v.k1 % CG_SC == 0 && v.cout % 128 == 0 && v.kreal == v.cin && !cv.dec && !getenv("AVHOT_CONV_NO_GEMM") &&
+                    !getenv("AVHOT_CONV_NO_GEMM_1X1"))     // layer 12's cv1 (384 -> 128): the GEMM form, both sources
+                    hipLaunchKernelGGL(conv_gemm128_kernel, dim3((v.npix + 63) / 64, v.cout / 128), dim3(256), (size_t)2 * (128 + 64) * CG_ROWB,
+                                       st_main, v);
+                else
                 hipLaunchKernelGGL((conv_lds_kernel<4, 1>), dim3(tiles_x * tiles_y * B, v.cout / 64), dim3(256), lds, st_main, v, tiles_x, tiles_y);
                 AV_LAUNCH_CHECK();
                 oi += 1;                                                                    // the cv1 op is done too
