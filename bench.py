@@ -4,13 +4,16 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 For N > 1 it is launched under torch.distributed.run, one rank per GPU (RCCL).
 
-Headline (default) = BASELINE config 4, the per-GPU share of config 5: 64 concurrent synthetic streams per GPU
-batched through detect (simulated) -> track -> Kalman step -> plan, one hipGraph replay per step, a step = one
-256-frame window of every stream, all inputs resident in HBM.  value = frames/s over all ranks.
+Headline (default) = BASELINE config 4 AS WORDED ("64 streams ... one graph launch per time-step"), the per-GPU
+share of config 5: 64 concurrent synthetic streams per GPU batched through detect (simulated) -> track -> Kalman step -> plan,
+a step = ONE TIME-STEP (one frame of every stream) = one launch of the one-kernel step av_hot_step (launched, not replayed:
+replaying a one-kernel graph costs 5 us more per step than launching the kernel), all inputs resident in HBM.
+value = frames/s over all ranks.  A reported "step" is timed over `inner_reps` back-to-back repetitions so that every figure
+rests on >= 0.2 s of device time (`--steps` is what the driver passes; ms_per_step = time / (steps x inner_reps)).
 
 At N = 1 the same JSON line carries, under "also", the other single-GPU configurations measured in the same process:
-  config4_w1   config 4 with window 1: one launch (av_hot_step) per TIME-STEP of 64 frames, eager -- replaying a one-kernel
-               graph costs 5 us more per step than launching the kernel (19.0 against 14.3 us)
+  config4_window256  the throughput form of config 4: 256-frame windows of every stream per step, one hipGraph replay per
+               window (needs the window's 256 future measurement frames: an offline / replay mode, not a live loop)
   config3      YOLO-mode detector (MFMA convs) + Canny/Hough lane detector on device-generated 1280x720 frames
   config2      1 stream, simulated detection (latency-bound: one dependent chain)
   config2_w1   config 2 with window 1
@@ -62,6 +65,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--native-allgather", action="store_true",
+                    help="N>1: gather with the library's own av_allgather_tracks (RCCL communicator made from a broadcast "
+                         "ncclUniqueId) instead of torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--min-seconds", type=float, default=0.2, help="least device time behind every reported figure")
     ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
                     help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
     ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step")
@@ -220,6 +227,18 @@ def finish_kernel_list(ks):
     return ks
 
 
+def pick_reps(est_step_s, steps, min_s, world):
+    """Inner repetitions per reported step so that the timed region lasts >= min_s; every rank uses rank 0's choice."""
+    import torch
+    import torch.distributed as dist
+    r = max(1, int(min_s / max(est_step_s * steps, 1e-9) + 0.999))
+    if world > 1:
+        t = torch.tensor([r], dtype=torch.int64, device="cuda")
+        dist.broadcast(t, 0)
+        r = int(t.item())
+    return r
+
+
 def max_over_ranks(el, world):
     import torch
     import torch.distributed as dist
@@ -256,7 +275,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     if world > 1 and not a.no_allgather:
         # window 1: every step IS a frame, so the per-frame gather (config 5's wording) is the default there -- and with the
         # one-launch step the wire tables come out of the step kernel itself (no pack launch)
-        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame" or W == 1))
+        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame" or W == 1), native=a.native_allgather)
     h, s = loop.ctx.handle, loop._s
     cross = xchg is not None or a.taggers     # somebody on the main stream reads the tracker's tables every step
 
@@ -294,14 +313,21 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         if xchg is not None:
             xchg.synchronize()
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, 1)):
         one_step()
     drain()
     torch.cuda.synchronize()
+    # a probe of the step's duration (untimed) sizes the inner repetitions: every reported step = `reps` back-to-back steps
+    tp = time.perf_counter()
+    for _ in range(8):
+        one_step()
+    drain()
+    torch.cuda.synchronize()
+    reps = pick_reps((time.perf_counter() - tp) / 8, steps, a.min_seconds, world)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps * reps):
         one_step()
     drain()
     torch.cuda.synchronize()
@@ -309,6 +335,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         dist.barrier()
     el = time.perf_counter() - t0
     el, per_rank_ms = max_over_ranks(el, world)
+    nsteps = steps * reps
 
     # the tracker's sticky overflow flag: a truncated table would silently drop births (parity lost)
     hdr, _, _ = loop.tracker_tables()
@@ -372,8 +399,9 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     if planner_k is not None and not loop.fused_step:
         roof["hbm_bound_kernel_beside_it"] = {k: planner_k[k] for k in ("kernel", "avg_ms", "achieved", "frac", "traffic", "bytes_per_launch")}
     step_bytes = (TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb
-    out = {"metric": METRIC, "value": round(F * steps * world / el, 1), "unit": "frames/s", "n_gpus": world,
-           "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 5), "higher_is_better": True,
+    out = {"metric": METRIC, "value": round(F * nsteps * world / el, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "inner_reps": reps, "timed_s": round(el, 4),
+           "ms_per_step": round(el / nsteps * 1e3, 6), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window per step, 1280x720, simulated detection + IoU "
                                   "tracker + 6-state KF + 21-candidate planner%s" % (name, S, W, ", one hipGraph replay per step" if graph else (", one launch per step" if W == 1 else "")),
@@ -386,7 +414,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
            "step": {"critical_branch": "side (detect+track)" if side > main else "main (kf+plan)",
                     "side_branch_ms": round(side, 5), "main_branch_ms": round(main, 5),
                     "algorithmic_bytes": step_bytes,
-                    "hbm_frac_whole_step": round(step_bytes / (el / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "hbm_frac_whole_step": round(step_bytes / (el / nsteps) / 1e9 / HBM_PEAK_GBS, 4)},
            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
     if xchg is not None:
         out["config"]["allgather_bytes_per_rank_per_step"] = xchg.bytes_per_step
@@ -394,7 +422,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         out["stage_kernels_replaced"] = stage_kernels
     out["traffic_profiles"] = [pmc_stamp("tracker_pmc.json"), pmc_stamp("planner_pmc.json")]
     if W == 1:
-        out["us_per_time_step"] = round(el / steps * 1e6, 3)
+        out["us_per_time_step"] = round(el / nsteps * 1e6, 3)
     del loop, xchg
     torch.cuda.empty_cache()
     return out
@@ -429,14 +457,21 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
         loop.enqueue_detect()
         nat.check(L.av_join(loop.ctx.handle, s))
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, 1)):
         one_step()
     loop.synchronize()
     torch.cuda.synchronize()
+    tp = time.perf_counter()
+    for _ in range(4):
+        one_step()
+    loop.synchronize()
+    torch.cuda.synchronize()
+    reps = pick_reps((time.perf_counter() - tp) / 4, steps, a.min_seconds, world)
+    nsteps = steps * reps
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(nsteps):
         one_step()
     loop.flush_lanes()            # the last frame's Hough half is flushed inside the timed region
     loop.synchronize()
@@ -486,8 +521,9 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     if "flops_per_launch" in dom:
         roof["flops_per_launch"] = dom["flops_per_launch"]
         roof["mfma_busy_pmc_percent"] = pmc_value("yolo_mfma_pmc.json", "overall_mfma_busy_percent")
-    out = {"metric": METRIC, "value": round(S * steps * world / el, 1), "unit": "frames/s", "n_gpus": world,
-           "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 4), "higher_is_better": True,
+    out = {"metric": METRIC, "value": round(S * nsteps * world / el, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "inner_reps": reps, "timed_s": round(el, 4),
+           "ms_per_step": round(el / nsteps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": loop.yolo.precision, "data": "synthetic (generated on device)",
            "config": {"workload": "config3: %d camera streams/GPU, one 1280x720 frame of each per step, YOLO-mode detector "
                                   "(random-init YOLOv8n topology, letterbox 384x640) + Canny/Hough lane detector" % S,
@@ -666,15 +702,20 @@ def main():
         g = bool(a.graph) if a.graph is not None else False
         head = with_cpu(hot("config2", a.streams or 1, a.window or 131072, g, a.steps, a.warmup), cpu_hot)
     else:
-        g = (a.window != 1) if a.graph is None else bool(a.graph)      # window 1 is one kernel: launched, not replayed
-        head = with_cpu(hot("config4", a.streams or 64, a.window or 256, g, a.steps, a.warmup), cpu_hot)
+        W = a.window or 1                                              # as worded: one launch per time-step
+        g = (W != 1) if a.graph is None else bool(a.graph)             # window 1 is one kernel: launched, not replayed
+        head = with_cpu(hot("config4" if W == 1 else "config4 (%d-frame windows)" % W, a.streams or 64, W, g, a.steps, a.warmup), cpu_hot)
 
     if world == 1 and not a.no_also and a.workload == "config4":
         also = {}
-        also["config4_w1"] = with_cpu(hot("config4 (window 1)", a.streams or 64, 1, False, 2000, 200), cpu_hot)
+        if (a.window or 1) == 1:
+            also["config4_window256"] = with_cpu(hot("config4, throughput form: 256-frame windows, one hipGraph replay per window",
+                                                     a.streams or 64, 256, True, 20, 5), cpu_hot)
+        else:
+            also["config4_w1"] = with_cpu(hot("config4 (window 1)", a.streams or 64, 1, False, 20, 5), cpu_hot)
         also["config3"] = with_cpu(run_config3(a, world, rank, local, 64, 20, 5), cpu_pix)
         also["config2"] = with_cpu(hot("config2", 1, 32768, False, 4, 1), cpu_hot)
-        also["config2_w1"] = with_cpu(hot("config2 (window 1)", 1, 1, False, 2000, 200), cpu_hot)
+        also["config2_w1"] = with_cpu(hot("config2 (window 1)", 1, 1, False, 20, 5), cpu_hot)
         also["config4_256streams"] = with_cpu(hot("config4 scaled to 256 streams (not a BASELINE config: shows the "
                                                   "HBM-bound regime once every CU has a tracker stream)", 256, 256, True, 10, 3), cpu_hot)
         also["per_frame_classes"] = run_per_frame_classes(local)

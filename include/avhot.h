@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AV_VERSION 100
+#define AV_VERSION 101
 
 enum {
     AV_OK = 0,
@@ -152,7 +152,7 @@ int av_tracker_update(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* cfg
 #define AV_WIRE_HDR_BYTES 16
 #define AV_WIRE_ROW_BYTES 32
 typedef struct {
-    int32_t n_rows, stream, frame, reserved;   /* global stream id, frame index within the run */
+    int32_t n_rows, stream, frame, reserved;   /* global stream id; frame: see av_pack_tracks */
 } av_wire_hdr;
 typedef struct {
     int32_t id;
@@ -167,11 +167,14 @@ size_t av_wire_table_bytes(int tcap);          /* AV_WIRE_HDR_BYTES + tcap * AV_
 /* Packs the tables of frames [frame_lo, frame_lo + n_sel) of every stream of a window into
  *   wire [n_streams][n_sel][av_wire_table_bytes(tcap)]
  * (n_sel = 1, frame_lo = n_frames - 1: the end-of-window table; n_sel = n_frames: every frame's table).
- * stream0 / frame0 are added to the header's stream / frame fields (this rank's first global stream id and the
- * window's first frame index).  The gather itself is torch.distributed's all_gather_into_tensor on `wire`
+ * header.stream = stream0 + s (this rank's first global stream id).  header.frame = frame0 + the stream's DETECTOR FRAME COUNT
+ * at that frame (ObjectDetector.frame_count after detect(), detector.py:96; 1 for a stream's first frame, plus whatever offset
+ * the counter was reset to) when `frame_count` [n_streams] -- the detector's counters after the window's last frame, as
+ * av_simdet_generate / av_hot_step leave them -- is given: the same value av_hot_step stamps.  frame_count NULL: frame0 + the
+ * frame's index within the window.  The gather itself is torch.distributed's all_gather_into_tensor on `wire`
  * (RCCL over xGMI; distributed.TrackTableExchange). */
 int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
-                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, void* wire);
+                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, const int32_t* frame_count, void* wire);
 
 /* The all-gather itself as a library call on an RCCL communicator (av_allgather_tracks(ctx, ncclComm_t, ...);
  * the reference has no counterpart).  `comm` is an ncclComm_t: the caller's own, or one made by av_comm_create from a

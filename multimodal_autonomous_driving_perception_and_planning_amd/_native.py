@@ -102,7 +102,7 @@ _SIGS = [
     ("av_tracker_update", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp,
                                     C.c_int, vp, vp, vp, vp]),
     ("av_wire_table_bytes", C.c_size_t, [C.c_int]),
-    ("av_pack_tracks", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    ("av_pack_tracks", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     ("av_comm_unique_id", C.c_int, [vp]),
     ("av_comm_create", C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
     ("av_comm_destroy", C.c_int, [vp]),

@@ -153,6 +153,37 @@ __device__ __forceinline__ unsigned long long wave_argmax_nonneg(double v, bool 
     const unsigned ml = wave_max_u32(top ? lo : 0u);
     return __ballot(top && lo == ml);
 }
+// ---- track-table wire format (include/avhot.h: av_wire_hdr / av_wire_row), the one device statement of it: used by
+// pack_tracks_kernel (exchange.hip) and by the one-launch step (step.hip) -------------------------------------------
+__device__ __forceinline__ av_wire_row wire_row_from(const av_track_row& in, bool live) {
+    av_wire_row o;
+    if (live) {
+        o.id = in.id;
+        o.x1 = (int16_t)in.x1, o.y1 = (int16_t)in.y1, o.x2 = (int16_t)in.x2, o.y2 = (int16_t)in.y2;
+        o.age = in.age, o.hits = in.hits;
+        o.misses = (uint16_t)(in.misses > 65535 ? 65535 : in.misses);
+        o.cls = (uint8_t)in.cls, o.flags = (uint8_t)in.flags;
+        o.conf = (float)in.conf;
+        // centre velocities are differences of half-integers: 2*v is an exact integer
+        o.vx2 = (int16_t)(in.vx * 2.0f), o.vy2 = (int16_t)(in.vy * 2.0f);
+    } else {
+        o.id = 0, o.x1 = o.y1 = o.x2 = o.y2 = 0, o.age = o.hits = 0, o.misses = 0, o.cls = 0, o.flags = 0, o.conf = 0.0f;
+        o.vx2 = o.vy2 = 0;
+    }
+    return o;
+}
+// row r of one table: `rows` = the table's tcap tracker rows, n its live count, dst the table's first wire byte
+__device__ __forceinline__ void wire_put(uint8_t* dst, int r, int n, int tcap, const av_track_row* rows, int stream, int frame) {
+    if (r == 0) {
+        av_wire_hdr h;
+        h.n_rows = n < tcap ? n : tcap, h.stream = stream, h.frame = frame, h.reserved = 0;
+        *reinterpret_cast<av_wire_hdr*>(dst) = h;
+    }
+    av_track_row in{};
+    if (r < n) in = rows[r];
+    reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = wire_row_from(in, r < n);
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

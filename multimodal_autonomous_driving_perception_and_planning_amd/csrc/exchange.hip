@@ -9,13 +9,15 @@
 
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
 // one thread per (table, row); tables are [n_streams][n_sel] selected frames of snap[n_streams][n_frames][tcap]
 __global__ void __launch_bounds__(256) pack_tracks_kernel(int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
                                                           int stream0, int frame0, const av_track_row* __restrict__ snap,
-                                                          const int32_t* __restrict__ snap_n, uint8_t* __restrict__ wire) {
+                                                          const int32_t* __restrict__ snap_n, const int32_t* __restrict__ frame_count,
+                                                          uint8_t* __restrict__ wire) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)n_streams * n_sel * tcap;
     if (i >= total) return;
@@ -23,33 +25,11 @@ __global__ void __launch_bounds__(256) pack_tracks_kernel(int n_streams, int n_f
     const long long t = i / tcap;                       // table index = s * n_sel + k
     const int s = (int)(t / n_sel), k = (int)(t - (long long)s * n_sel);
     const int f = frame_lo + k;
-    const int n = snap_n[(size_t)s * n_frames + f];
     const size_t tb = AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES;
-    uint8_t* dst = wire + (size_t)t * tb;
-    if (r == 0) {
-        av_wire_hdr h;
-        h.n_rows = n < tcap ? n : tcap;
-        h.stream = stream0 + s;
-        h.frame = frame0 + f;
-        h.reserved = 0;
-        *reinterpret_cast<av_wire_hdr*>(dst) = h;
-    }
-    av_wire_row o;
-    if (r < n) {
-        const av_track_row in = snap[((size_t)s * n_frames + f) * tcap + r];
-        o.id = in.id;
-        o.x1 = (int16_t)in.x1, o.y1 = (int16_t)in.y1, o.x2 = (int16_t)in.x2, o.y2 = (int16_t)in.y2;
-        o.age = in.age, o.hits = in.hits;
-        o.misses = (uint16_t)(in.misses > 65535 ? 65535 : in.misses);
-        o.cls = (uint8_t)in.cls, o.flags = (uint8_t)in.flags;
-        o.conf = (float)in.conf;
-        // centre velocities are differences of half-integers: 2*v is an exact integer
-        o.vx2 = (int16_t)(in.vx * 2.0f), o.vy2 = (int16_t)(in.vy * 2.0f);
-    } else {
-        o.id = 0, o.x1 = o.y1 = o.x2 = o.y2 = 0, o.age = o.hits = 0, o.misses = 0, o.cls = 0, o.flags = 0, o.conf = 0.0f;
-        o.vx2 = o.vy2 = 0;
-    }
-    reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = o;
+    // header.frame: with the detector's counters, the stream's detector frame count at frame f (the counter holds the count
+    // after the window's last frame) -- what the one-launch step stamps; without them, the index within the window
+    const int frame = frame_count ? frame0 + frame_count[s] - (n_frames - 1 - f) : frame0 + f;
+    wire_put(wire + (size_t)t * tb, r, snap_n[(size_t)s * n_frames + f], tcap, snap + ((size_t)s * n_frames + f) * tcap, stream0 + s, frame);
 }
 
 // ---- RCCL, opened on demand (no link-time dependency) ---------------------------------------------------------------------
@@ -62,14 +42,23 @@ struct Rccl {
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
 };
+char g_rccl_why[256] = "symbols missing";     // why rccl() returned null (dlerror() is cleared by reading it: kept once)
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // RTLD_NOLOAD first: inside a torch process this is torch's own copy of the library, not a second one beside it
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
-            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (r.so) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            if (r.so) break;
+            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.so) {
+                const char* e = dlerror();
+                if (e) snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", e);
+            }
         }
         if (r.so) {
             r.get_unique_id = reinterpret_cast<int (*)(NcclId*)>(dlsym(r.so, "ncclGetUniqueId"));
@@ -78,7 +67,7 @@ Rccl* rccl() {
             r.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.so, "ncclAllGather"));
             r.error_string = reinterpret_cast<const char* (*)(int)>(dlsym(r.so, "ncclGetErrorString"));
         }
-    }
+    });
     return (r.so && r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_gather) ? &r : nullptr;
 }
 #define AV_RCCL(call, what)                                                                                          \
@@ -97,7 +86,7 @@ extern "C" {
 size_t av_wire_table_bytes(int tcap) { return AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES; }
 
 int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames, int tcap, int frame_lo, int n_sel,
-                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, void* wire) {
+                   int stream0, int frame0, const av_track_row* snap, const int32_t* snap_n, const int32_t* frame_count, void* wire) {
     AV_REQUIRE(ctx && snap && snap_n && wire, AV_EINVAL, "av_pack_tracks: null argument");
     AV_REQUIRE(n_streams > 0 && n_frames > 0 && tcap > 0 && tcap <= 1024, AV_EINVAL, "av_pack_tracks: bad dimensions");
     AV_REQUIRE(frame_lo >= 0 && n_sel > 0 && frame_lo + n_sel <= n_frames, AV_EINVAL,
@@ -106,7 +95,7 @@ int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames,
     const long long total = (long long)n_streams * n_sel * tcap;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(pack_tracks_kernel, dim3(grid), dim3(256), 0, as_stream(stream), n_streams, n_frames, tcap,
-                       frame_lo, n_sel, stream0, frame0, snap, snap_n, (uint8_t*)wire);
+                       frame_lo, n_sel, stream0, frame0, snap, snap_n, frame_count, (uint8_t*)wire);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -114,7 +103,7 @@ int av_pack_tracks(av_ctx* ctx, av_stream_t stream, int n_streams, int n_frames,
 int av_comm_unique_id(void* id128) {
     AV_REQUIRE(id128, AV_EINVAL, "av_comm_unique_id: null argument");
     Rccl* R = rccl();
-    AV_REQUIRE(R, AV_ESTATE, "av_comm_unique_id: librccl could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+    AV_REQUIRE(R, AV_ESTATE, "av_comm_unique_id: librccl could not be opened (%s)", g_rccl_why);
     AV_RCCL(R->get_unique_id(reinterpret_cast<NcclId*>(id128)), "ncclGetUniqueId");
     return AV_OK;
 }

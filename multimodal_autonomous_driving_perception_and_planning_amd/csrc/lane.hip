@@ -1601,13 +1601,15 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
                                                      HoughCfg cfg, unsigned* __restrict__ nz_all,
                                                      const int* __restrict__ npts, int* __restrict__ accum_all,
                                                      const float* __restrict__ trig, int* __restrict__ segs,
-                                                     int* __restrict__ nseg, const int* __restrict__ fallback) {
+                                                     int* __restrict__ nseg, const int* __restrict__ fallback,
+                                                     int* __restrict__ path) {
     __shared__ int w_key[3];
     __shared__ int sh_pt[2];
     __shared__ unsigned long long flags[64];           // mask bits of 4096 walk steps
     __shared__ int ends[2][3];                          // x, y, step index of the line end
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (fallback && fallback[s] == 0) return;            // handled by houghp_fast
+    if (tid == 0) path[s] = 3;                           // (which kernel made the frame's segments: read by the tests)
     uint8_t* mask = masked + (size_t)s * h * w;
     unsigned* nz = nz_all + (size_t)s * h * w;
     int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
@@ -1765,7 +1767,7 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
                                                    const unsigned* __restrict__ nz_all, const int* __restrict__ npts,
                                                    int* __restrict__ accum_all, const float* __restrict__ trig,
                                                    int* __restrict__ segs, int* __restrict__ nseg,
-                                                   int* __restrict__ fallback, int check_flag) {
+                                                   int* __restrict__ fallback, int check_flag, int* __restrict__ path) {
     __shared__ unsigned nz[NZCAP];
     __shared__ unsigned bm[BMWORDS];
     __shared__ int fifo[FIFO];             // points drawn from the list but not voted yet (ring buffer)
@@ -1792,7 +1794,7 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
         if (tid == 0) fallback[s] = 1;
         return;
     }
-    if (tid == 0) fallback[s] = 0, sh_head = 0, sh_tail = 0, sh_count = total;
+    if (tid == 0) fallback[s] = 0, path[s] = 2, sh_head = 0, sh_tail = 0, sh_count = total;
     for (int i = tid; i < (ymax - ymin + 1) * wpr; i += 192) bm[i] = 0;
     __syncthreads();
     for (int i = tid; i < total; i += 192) {
@@ -2089,7 +2091,7 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
 constexpr int HG = 4;
 constexpr int HS_NZ = 4096, HS_BMW = 11776, HS_ACCW = 24576;      // LDS capacities: points, bitmap words, accumulator words
 constexpr unsigned HS_BIAS = 0x4000u;
-constexpr int HS_SPIN = 1 << 20;
+constexpr int HS_SPIN = 1 << 20;              // default bound of every exchange spin (x s_sleep 2), ~0.1 s; AVHOT_HOUGH_SPIN overrides it
 
 __global__ void hough_prep_kernel(int n_streams, int numrho, int* __restrict__ accum_all, int* __restrict__ fallback) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2116,7 +2118,10 @@ __device__ const HoughDraws g_draws = hough_draws();
 __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
-                                                   int* __restrict__ nseg, int* __restrict__ fallback) {
+                                                   int* __restrict__ nseg, int* __restrict__ fallback, int spin_limit,
+                                                   int drop_frame, int* __restrict__ path) {
+    // spin_limit: iterations an exchange waits for a partner before the frame is handed to houghp_fast; drop_frame (tests only,
+    // AVHOT_HOUGH_DROP): shard HG-1 of that frame never publishes its first exchange word, so its partners run into the limit
     __shared__ unsigned acc[HS_ACCW];
     __shared__ unsigned nz[HS_NZ];
     __shared__ unsigned bm[HS_BMW];
@@ -2253,14 +2258,15 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
     auto exchange = [&](int round, unsigned payload, unsigned (&got)[HG]) -> bool {
         unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
         unsigned long long wv = ((unsigned long long)seq << 32) | payload;
-        if (lane == 0) __hip_atomic_store(slot + g, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool dropped = s == drop_frame && g == HG - 1 && seq == 1u && round == 0;
+        if (lane == 0 && !dropped) __hip_atomic_store(slot + g, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true;
         if (lane < HG && lane != g) {
             int it = 0;
             for (;;) {
                 wv = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(wv >> 32) == seq) break;
-                if (++it > HS_SPIN) {
+                if (++it > spin_limit) {
                     ok = false;
                     break;
                 }
@@ -2521,7 +2527,7 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         }
     }
     finish();
-    if (g == 0 && lane == 0) nseg[s] = nlines;
+    if (g == 0 && lane == 0) nseg[s] = nlines, path[s] = 1;
 }
 
 // ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
@@ -2692,6 +2698,7 @@ int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segmen
         case 5: *offset = L.segs, *bytes = (size_t)n_streams * max_segments * 16; break;
         case 6: *offset = L.nseg, *bytes = (size_t)n_streams * 4; break;
         case 7: *offset = L.accum, *bytes = (size_t)n_streams * NUMANGLE * L.numrho * 4; break;
+        case 8: *offset = L.rowcnt + (size_t)n_streams * 4, *bytes = (size_t)n_streams * 4; break;     // Hough kernel taken per frame
         default: av_set_error("av_lane_workspace_view: unknown view %d", what); return AV_EINVAL;
     }
     return AV_OK;
@@ -2856,7 +2863,8 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
-    int* fb = rowcnt;       // the per-row counters are dead after compaction: reuse [s*h] as the fallback flag
+    int* fb = rowcnt;       // the per-row counters are dead after compaction: their first n_streams words are the fallback flags,
+    int* hpath = rowcnt + n_streams;   // the next n_streams say which kernel made a frame's segments (1 shard, 2 fast, 3 generic)
     const bool use_fast = !(stages & 8);
     if (use_fast) {
         // theta-sharded LDS variant first (4 workgroups per frame); frames it cannot hold, or where a partner did not
@@ -2867,16 +2875,19 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         if (use_shard) {
             hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 32 + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
             AV_LAUNCH_CHECK();
+            const char* sp = getenv("AVHOT_HOUGH_SPIN");
+            const char* dr = getenv("AVHOT_HOUGH_DROP");
+            const int spin = sp && atoi(sp) > 0 ? atoi(sp) : HS_SPIN;
             hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3(128), 0, st, h, w, L.numrho, hc, nz, npts, accum,
-                               lc->d_trig, segs, nseg, fb);
+                               lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath);
             AV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
-                           segs, nseg, fb, use_shard ? 1 : 0);
+                           segs, nseg, fb, use_shard ? 1 : 0, hpath);
         AV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
-                       lc->d_trig, segs, nseg, use_fast ? fb : nullptr);
+                       lc->d_trig, segs, nseg, use_fast ? fb : nullptr, hpath);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(lane_fit_kernel, dim3(n_streams * 2), dim3(64), 0, st, n_streams, h, w,
                        cfg->max_segments, cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);

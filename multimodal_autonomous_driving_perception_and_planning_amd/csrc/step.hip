@@ -49,33 +49,11 @@ __global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
                                         a.det2trk, 1, s, smem);
         if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
             __syncthreads();          // the snapshot rows the bookkeeper wave wrote
-            const int r = tid;
-            if (r < a.tcap) {
-                const int n = a.snap_n[s];
-                uint8_t* dst = a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES);
-                if (r == 0) {
-                    av_wire_hdr hd;
-                    // frame = frame0 + the stream's detector frame count after this step: read from memory, so that a captured graph
-                    // (fixed kernel arguments) stamps every replay with its own index
-                    hd.n_rows = n < a.tcap ? n : a.tcap, hd.stream = a.stream0 + s, hd.frame = a.frame0 + a.frame_count[s], hd.reserved = 0;
-                    *reinterpret_cast<av_wire_hdr*>(dst) = hd;
-                }
-                av_wire_row o;
-                if (r < n) {
-                    const av_track_row in = a.snap[(size_t)s * a.tcap + r];
-                    o.id = in.id;
-                    o.x1 = (int16_t)in.x1, o.y1 = (int16_t)in.y1, o.x2 = (int16_t)in.x2, o.y2 = (int16_t)in.y2;
-                    o.age = in.age, o.hits = in.hits;
-                    o.misses = (uint16_t)(in.misses > 65535 ? 65535 : in.misses);
-                    o.cls = (uint8_t)in.cls, o.flags = (uint8_t)in.flags;
-                    o.conf = (float)in.conf;
-                    o.vx2 = (int16_t)(in.vx * 2.0f), o.vy2 = (int16_t)(in.vy * 2.0f);
-                } else {
-                    o.id = 0, o.x1 = o.y1 = o.x2 = o.y2 = 0, o.age = o.hits = 0, o.misses = 0, o.cls = 0, o.flags = 0, o.conf = 0.0f;
-                    o.vx2 = o.vy2 = 0;
-                }
-                reinterpret_cast<av_wire_row*>(dst + AV_WIRE_HDR_BYTES)[r] = o;
-            }
+            // frame = frame0 + the stream's detector frame count after this step: read from memory, so that a captured graph
+            // (fixed kernel arguments) stamps every replay with its own index
+            if (tid < a.tcap)
+                wire_put(a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES), tid, a.snap_n[s], a.tcap,
+                         a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + a.frame_count[s]);
         }
     } else {
         const int s = blockIdx.x - a.S;
@@ -124,7 +102,13 @@ extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
     const size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
     const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, STEP_NW) * 8;
     const size_t lds = lds_t > lds_p ? lds_t : lds_p;
-    AV_REQUIRE(lds <= 64 * 1024, AV_EINVAL, "av_hot_step: configuration needs %zu B of LDS", lds);
+    // static __shared__ of the kernel (the Kalman bodies' arrays) counts against the same 64 KB
+    static const size_t lds_static = [] {
+        hipFuncAttributes fa{};
+        return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(hot_step_kernel)) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)16384;
+    }();
+    AV_REQUIRE(lds + lds_static <= 64 * 1024, AV_EINVAL, "av_hot_step: configuration needs %zu B of dynamic + %zu B of static LDS (limit 65536)",
+               lds, lds_static);
     hipLaunchKernelGGL(hot_step_kernel, dim3(2 * n_streams), dim3(STEP_NW * 64), lds, as_stream(stream), a);
     AV_LAUNCH_CHECK();
     return AV_OK;

@@ -23,6 +23,7 @@
 // and does every global write; the others carry just what column ownership needs: boxes, miss counters
 // and the row count, kept in step by the same matches, births and order-preserving compactions.
 // Windows (PIPE): the complete rows move to a ninth wave that trails the column waves by one frame -- see tracker_body.
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -699,11 +700,18 @@ template <bool TIMED, int PIPE>
 int launch_replicas(int n_streams, size_t lds, hipStream_t st, const av_tracker_cfg& cfg, int n_frames, int dcap, const int32_t* det_n,
                     const int32_t* det_box, const int32_t* det_cls, const double* det_conf, int tcap, unsigned char* state,
                     av_track_row* snap, int32_t* snap_n, int32_t* det2trk, int fc) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tracker_kernel<false, 8, 8, TIMED, PIPE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // per device (the attribute belongs to the device's copy of the function): once for each device this process launches on
+    static std::mutex mu;
+    static unsigned long long devs_done = 0;
+    int dev = 0;
+    AV_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !((devs_done >> dev) & 1ull)) {
+            AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tracker_kernel<false, 8, 8, TIMED, PIPE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev >= 0 && dev < 64) devs_done |= 1ull << dev;
+        }
     }
     // hardware wave -> role.  SIMD of hardware wave h = h % 4.  With the trailing wave: SIMD 0 = column 0 + columns 6, 7; SIMD 1 = the
     // trailing wave + column 3; SIMD 2 = columns 1, 4; SIMD 3 = columns 2, 5 (0.268 -> 0.260 ms per 64 x 256 frames).

@@ -45,10 +45,11 @@ def wire_table_bytes(tcap):
     return WIRE_HDR_BYTES + tcap * WIRE_ROW_BYTES
 
 
-def pack_wire(snap_u8, snap_n, frame_lo, n_sel, stream0=0, frame0=0):
+def pack_wire(snap_u8, snap_n, frame_lo, n_sel, stream0=0, frame0=0, frame_count=None):
     """Host/torch statement of av_pack_tracks (the HIP kernel is checked against it bit for bit; the CPU tests and
     CPU-tensor exchanges use it directly).  snap_u8 [S, W, tcap, 64] uint8, snap_n [S, W] int32 ->
-    [S, n_sel, wire_table_bytes(tcap)] uint8."""
+    [S, n_sel, wire_table_bytes(tcap)] uint8.  header.frame = frame0 + the stream's detector frame count at that frame when
+    `frame_count` [S] (the counters after the window's last frame) is given, else frame0 + the index within the window."""
     S, W, tcap, _ = snap_u8.shape
     sel = snap_u8[:, frame_lo:frame_lo + n_sel].contiguous()
     n = snap_n[:, frame_lo:frame_lo + n_sel].to(torch.int32).clamp(max=tcap).contiguous()
@@ -74,6 +75,8 @@ def pack_wire(snap_u8, snap_n, frame_lo, n_sel, stream0=0, frame0=0):
     hdr[..., 0] = n
     hdr[..., 1] = stream0 + torch.arange(S, device=sel.device, dtype=torch.int32).view(S, 1)
     hdr[..., 2] = frame0 + frame_lo + torch.arange(n_sel, device=sel.device, dtype=torch.int32).view(1, n_sel)
+    if frame_count is not None:
+        hdr[..., 2] += frame_count.to(device=sel.device, dtype=torch.int32).view(S, 1) - (W - 1)
     msg = torch.empty(S, n_sel, wire_table_bytes(tcap), dtype=torch.uint8, device=sel.device)
     msg[..., :WIRE_HDR_BYTES] = hdr.view(torch.uint8).reshape(S, n_sel, WIRE_HDR_BYTES)
     msg[..., WIRE_HDR_BYTES:] = out.reshape(S, n_sel, tcap * WIRE_ROW_BYTES)
@@ -138,6 +141,11 @@ class TrackTableExchange:
         self.recv = [torch.zeros(world * S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
         if native is None:
             native = os.environ.get("AVHOT_NATIVE_ALLGATHER", "0") == "1"
+        if native and not self.gpu:
+            import warnings
+            warnings.warn("TrackTableExchange(native=True) needs device tensors (av_allgather_tracks is an RCCL call); "
+                          "this loop's tables are on the CPU, so the gather goes through torch.distributed instead",
+                          RuntimeWarning, stacklevel=2)
         self.native = bool(native) and self.gpu
         self.nccl = None
         if self.gpu:
@@ -160,34 +168,47 @@ class TrackTableExchange:
         # window 1 with the one-launch step (HotLoop.fused_step): the step kernel itself writes the wire tables, straight into
         # the send buffer handed to it by begin_step() -- no pack launch between the step and the gather
         self.prepacked = bool(getattr(loop, "fused_step", False)) and loop.W == 1
+        self._handed = None             # the send buffer begin_step() handed to the loop for the step being enqueued
 
     def begin_step(self):
-        """Call BEFORE enqueuing step k when `prepacked`: hands send buffer k & 1 to the loop (after the gather that last read it)."""
+        """Call BEFORE enqueuing step k when `prepacked`: hands send buffer k & 1 to the loop (after the gather that last read it).
+        A step enqueued without it is still exchanged correctly -- exchange() then packs the tables itself."""
         if not self.prepacked:
             return
         b = self.k & 1
         if self.gpu and self.done[b] is not None:
             self.loop.stream.wait_event(self.done[b])
         self.loop.set_wire(self.send[b].view(self.loop.S, -1), stream0=self.rank * self.loop.S, frame0=0)
+        self._handed = b
 
     def exchange(self):
         """Enqueue pack + all-gather of the step just enqueued on loop.stream; returns the receive buffer
         ([world*S, n_sel, table bytes], complete once synchronize() / latest() returns)."""
         b = self.k & 1
         loop = self.loop
-        frame0 = self.k * loop.W
+        # header.frame: the stream's detector frame count at that frame when the loop keeps the counters (HotLoop does -- the value
+        # the one-launch step stamps as well), else the number of frames exchanged before it
+        fcount = getattr(loop, "frame_count", None)
+        frame0 = 0 if fcount is not None else self.k * loop.W
+        # prepacked: the step just enqueued wrote its wire tables into send[b] -- if begin_step() handed it that buffer.  If the
+        # caller skipped begin_step() the tables are packed here like in any other mode (never a stale or empty buffer).
+        prepacked = self.prepacked and self._handed == b and getattr(loop, "wire", None) is not None \
+            and loop.wire.data_ptr() == self.send[b].data_ptr()
+        self._handed = None
+        if self.prepacked:
+            loop.set_wire(None)                    # a later step without begin_step() must not write into a buffer being gathered
         if not self.gpu:
-            if not self.prepacked:
-                self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0))
+            if not prepacked:
+                self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0, fcount))
             dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             self.k += 1
             return self.recv[b]
-        if not self.prepacked:
+        if not prepacked:
             if self.done[b] is not None:           # buffer b is still being sent from two steps ago
                 loop.stream.wait_event(self.done[b])
             nat.check(nat.lib().av_pack_tracks(loop.ctx.handle, nat.stream_handle(loop.stream), loop.S, loop.W, loop.tcap,
                                                self.frame_lo, self.n_sel, self.rank * loop.S, frame0, nat.ptr(loop.snap),
-                                               nat.ptr(loop.snap_n), nat.ptr(self.send[b])))
+                                               nat.ptr(loop.snap_n), nat.ptr(fcount), nat.ptr(self.send[b])))
         self.ready[b].record(loop.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])

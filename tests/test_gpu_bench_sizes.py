@@ -1,0 +1,254 @@
+"""The configurations bench.py TIMES, checked against the oracle at the size they are timed at (round-3 verdict, weak #2):
+
+  * BASELINE config 4 as worded -- 64 streams, one launch per time-step (HotLoop(64, 1), av_hot_step) -- and its throughput
+    form, 64 streams x 256-frame windows replayed as a hipGraph: EVERY stream and EVERY frame against oracle.harness_ref
+    (demo.py:97-120 call order): detections, track ids / boxes / counters, det -> track assignment bit for bit; Kalman state
+    and plan costs to rtol 1e-9; candidate order equivalent up to near-ties;
+  * BASELINE config 3 -- PerceptionLoop(64) stepped the way bench.py steps it (Hough half one step late, detector tail
+    deferred): all 64 cameras' segments and fits against the C lane oracle (lane_detector.py:92-176), detections against
+    the single-image detector path;
+  * the sharded PPHT's spin-timeout hand-over to houghp_fast (lane.hip), forced by a debug knob.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from _util import orders_equivalent
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    t = pytest.importorskip("torch")
+    if not t.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return t
+
+
+@pytest.fixture(scope="module")
+def oracle_streams():
+    """64 oracle streams x 512 frames (bench.py's stream phases: detector offset 17 s, ego seed s); ~25 s of NumPy, once."""
+    from oracle.harness_ref import run_stream
+    return [run_stream(512, frame_offset=17 * s, ego_seed=s) for s in range(64)]
+
+
+def _check_window(r, rows, n, want, f0, W, where):
+    """One window [f0, f0 + W) of every stream against the oracle records."""
+    S = len(want)
+    for s in range(S):
+        w = want[s]
+        sl = slice(f0, f0 + W)
+        assert np.array_equal(r["det_n"][s], w["det_n"][sl]), (where, s)
+        assert np.array_equal(r["det_box"][s][:, :w["det_box"].shape[1]], w["det_box"][sl]), (where, s)
+        assert np.array_equal(r["det_conf"][s][:, :w["det_conf"].shape[1]], w["det_conf"][sl]), (where, s)
+        assert np.array_equal(n[s], w["n_live"][sl]), (where, s)
+        live = np.arange(rows.shape[2])[None, :] < n[s][:, None]                     # [W, tcap]
+        assert np.array_equal(np.where(live, rows[s]["id"], -1), np.where(live, w["ids"][sl], -1)), (where, s)
+        got_box = np.stack([rows[s][k] for k in ("x1", "y1", "x2", "y2")], axis=2)
+        assert np.array_equal(got_box[live], w["tbox"][sl][live]), (where, s)
+        got_ahm = np.stack([rows[s][k] for k in ("age", "hits", "misses")], axis=2)
+        assert np.array_equal(got_ahm[live], w["ahm"][sl][live]), (where, s)
+        nd = w["det2trk"].shape[1]
+        dlive = np.arange(nd)[None, :] < w["det_n"][sl][:, None]
+        assert np.array_equal(r["det2trk"][s][:, :nd][dlive], w["det2trk"][sl][dlive]), (where, s)
+        np.testing.assert_allclose(r["vstate"][s], w["state"][sl], rtol=1e-9, atol=1e-9, err_msg="%s stream %d" % (where, s))
+        np.testing.assert_allclose(r["cost"][s], w["cost"][sl], rtol=1e-9, err_msg="%s stream %d" % (where, s))
+        for f in range(W):
+            assert orders_equivalent(w["cost"][f0 + f], w["order"][f0 + f], r["order"][s, f]), (where, s, f)
+            np.testing.assert_allclose(r["wp"][s, f, r["order"][s, f, 0]], w["best_wp"][f0 + f], rtol=1e-9, atol=1e-9)
+
+
+def test_config4_window256_graph_every_stream_and_frame(torch, oracle_streams):
+    """also.config4_window256 at its bench size: HotLoop(64, 256), two graph replays on the carried state (the second
+    window starts from the first one's tables, Kalman records and detector counters)."""
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    S, W = 64, 256
+    want = oracle_streams
+    loop = HotLoop(n_streams=S, window=W)
+    loop.reset(frame_offsets=[17 * s for s in range(S)])
+    for win in range(2):
+        loop.load_measurements(np.stack([w["z"][win * W:(win + 1) * W] for w in want]))
+        loop.step(graph=True, sync=True)
+        rows, n = loop.snapshots()
+        _check_window(loop.results(), rows, n, want, win * W, W, "window %d" % win)
+    hdr, _, _ = loop.tracker_tables()
+    assert not hdr[:, 3].any()                                              # no table overflow at tcap 64
+
+
+def test_config4_as_worded_one_launch_per_time_step_every_stream(torch, oracle_streams):
+    """The headline: 64 streams, one av_hot_step launch per time-step, launched back to back without host synchronisation
+    (as the bench's timed loop does) -- 200 time-steps, every stream's every frame against the oracle.  The measurement
+    frame of step t is uploaded on the loop's stream before the step (stream-ordered), outputs are copied out per step."""
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    S, T = 64, 200
+    want = oracle_streams
+    loop = HotLoop(n_streams=S, window=1)
+    assert loop.fused_step
+    loop.reset(frame_offsets=[17 * s for s in range(S)])
+    z_all = torch.as_tensor(np.stack([w["z"][:T] for w in want])).to(loop.dev)          # [S, T, 4]
+    keep = {k: [] for k in ("det_n", "det_box", "det_conf", "det2trk", "vstate", "cost", "order", "wp", "snap", "snap_n")}
+    with torch.cuda.stream(loop.stream):
+        for t in range(T):
+            loop.z.copy_(z_all[:, t:t + 1])
+            loop.enqueue_step()
+            for k in keep:
+                keep[k].append(getattr(loop, k).clone())
+    loop.synchronize()
+    cat = {k: torch.stack(v, dim=1).cpu().numpy() for k, v in keep.items()}
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    r = dict(det_n=cat["det_n"].reshape(S, T), det_box=cat["det_box"].reshape(S, T, loop.dcap, 4),
+             det_conf=cat["det_conf"].reshape(S, T, loop.dcap), det2trk=cat["det2trk"].reshape(S, T, loop.dcap),
+             vstate=cat["vstate"].reshape(S, T, -1), cost=cat["cost"].reshape(S, T, loop.n_cand),
+             order=cat["order"].reshape(S, T, loop.n_cand), wp=cat["wp"].reshape(S, T, loop.n_cand, loop.n_points, 6))
+    rows = np.ascontiguousarray(cat["snap"]).view(np.dtype(nat.TRACK_ROW_FIELDS)).reshape(S, T, loop.tcap)
+    _check_window(r, rows, cat["snap_n"].reshape(S, T), want, 0, T, "window-1 steps")
+
+
+def test_prepacked_exchange_around_the_fused_step(torch, oracle_streams):
+    """HotLoop(window=1) puts TrackTableExchange in `prepacked` mode -- the step kernel writes the wire
+    tables into the send buffer begin_step() hands it.  One rank, eager and graph, torch.distributed and native gather: the
+    gathered tables equal the loop's snapshots step after step (and the oracle's track ids); and a caller that forgets
+    begin_step() still gets the right tables (exchange() falls back to the pack kernel) instead of stale ones."""
+    import torch.distributed as dist
+    from multimodal_autonomous_driving_perception_and_planning_amd import distributed as D
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    S, T = 8, 12
+    want = oracle_streams[:S]
+    try:
+        for graph in (False, True):
+            for native in (False, True):
+                for forget in (False, True):
+                    loop = HotLoop(n_streams=S, window=1, keep_waypoints=False)
+                    loop.reset(frame_offsets=[17 * s for s in range(S)])
+                    x = D.TrackTableExchange(loop, 1, 0, per_frame=True, native=native)
+                    assert x.prepacked and x.native == native
+                    try:
+                        for t in range(T):
+                            loop.load_measurements(np.stack([w["z"][t:t + 1] for w in want]))
+                            if not forget:
+                                x.begin_step()
+                            loop.step(graph=graph)
+                            x.exchange()
+                            hdr, rows = x.latest()
+                            srows, sn = loop.snapshots()
+                            for s in range(S):
+                                m = sn[s, 0]
+                                assert hdr["n_rows"][s, 0] == m == want[s]["n_live"][t], (graph, native, forget, t, s)
+                                assert hdr["stream"][s, 0] == s and hdr["frame"][s, 0] == 17 * s + t + 1
+                                assert np.array_equal(rows[s, 0]["id"][:m], want[s]["ids"][t][:m])
+                                for k in ("id", "x1", "y1", "x2", "y2", "age", "hits", "misses", "cls", "flags"):
+                                    assert np.array_equal(rows[s, 0][k][:m], srows[s, 0][k][:m]), k
+                                assert not rows[s, 0][m:].view(np.uint8).any()
+                    finally:
+                        x.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_bench_size_all_64_cameras(torch):
+    """bench.py's config-3 step at its size: 64 cameras, frames generated on the device, lane chain beside the detector on
+    the side stream with its Hough + fit half one step late (256 co-resident houghp_shard workgroups next to LDS-hungry
+    convolutions), detector tail deferred onto its own stream.  After three steps + flush every camera's segments, fits and
+    sampled points must be the C oracle's (EMA carried over the three frames) and its detections those of the single-image
+    detector path on the same frame."""
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.perception import yolo as Y
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import PerceptionLoop
+    from oracle.lane_ref import LaneRef, synthetic_frame
+    S, h, w, steps = 64, 720, 1280, 3
+    loop = PerceptionLoop(n_streams=S, h=h, w=w)
+    loop.defer_detector_tail(True)
+    refs = [LaneRef() for _ in range(S)]
+    wants = None
+    for step in range(steps):
+        loop.step_deferred()
+        wants = [refs[s].detect(synthetic_frame(h, w, s, step)) for s in range(S)]     # host work overlaps the device's
+    loop.flush_lanes()
+    loop.synchronize()
+    torch.cuda.synchronize()
+    L = nat.lib()
+
+    def view(what, dtype, shape):
+        off, nb = C.c_size_t(), C.c_size_t()
+        nat.check(L.av_lane_workspace_view(what, S, h, w, loop.ms, C.byref(off), C.byref(nb)))
+        return loop.ws[off.value:off.value + nb.value].cpu().numpy().view(dtype).reshape(shape)
+
+    frames = loop.frames.cpu().numpy()
+    segs, nseg, path = view(5, np.int32, (S, loop.ms, 4)), view(6, np.int32, (S,)), view(8, np.int32, (S,))
+    info, poly, pts, conf = loop.info.cpu().numpy(), loop.poly.cpu().numpy(), loop.pts.cpu().numpy(), loop.conf.cpu().numpy()
+    n, box, dconf, cls = (loop.det_n.cpu().numpy(), loop.det_box.cpu().numpy(), loop.det_conf.cpu().numpy(),
+                          loop.det_cls.cpu().numpy())
+    single = Y.YoloV8n("random:0")
+    for s in range(S):
+        assert np.array_equal(frames[s], synthetic_frame(h, w, s, steps - 1)), s
+        want = wants[s]
+        assert nseg[s] == len(want["segments"]) and np.array_equal(segs[s, :nseg[s]], want["segments"]), s
+        assert path[s] in (1, 2, 3), (s, path[s])
+        for side, exp in ((0, want["left"]), (1, want["right"])):
+            assert bool(info[s, side]) == (exp is not None), (s, side)
+            if exp is not None:
+                np.testing.assert_allclose(poly[s, side], exp[2], rtol=1e-6, atol=1e-6)
+                assert conf[s, side] == exp[1]
+                assert np.abs(pts[s, side] - exp[0]).max() <= 1
+        sb, sc, sk = single.detect(frames[s])
+        assert n[s] == len(sc) > 0, s
+        assert np.array_equal(box[s, :n[s]], sb) and np.array_equal(dconf[s, :n[s]], sc) and np.array_equal(cls[s, :n[s]], sk), s
+    single.close()
+    # the frames were sized for the sharded kernel: it is the one that ran, unless a partner did not show up in time
+    assert (path == 1).sum() >= S // 2, np.bincount(path, minlength=4)
+
+
+def test_sharded_hough_spin_timeout_hands_the_frame_to_houghp_fast(torch, monkeypatch):
+    """houghp_shard's four workgroups per frame meet through agent-scope exchange words; every spin is bounded and a
+    timeout flags the frame for houghp_fast.  Debug knobs (read per launch): AVHOT_HOUGH_DROP=f makes shard 3 of frame f
+    withhold its first exchange word, AVHOT_HOUGH_SPIN shortens the bound.  Frame f's three other shards time out, shard 3
+    times out one exchange later, and the frame must still come out with the oracle's segments -- made by houghp_fast --
+    while its neighbours stay on the sharded kernel."""
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from oracle.lane_ref import LaneRef, synthetic_frame
+    h, w, MS = 720, 1280, 512
+    frames = [synthetic_frame(h, w, s, 3) for s in (0, 5, 2, 7, 3)]
+    S = len(frames)
+    ctx, L, sh = nat.default_context(0), nat.lib(), nat.stream_handle()
+    dev = torch.device("cuda", 0)
+    bgr = torch.as_tensor(np.stack(frames)).to(dev)
+    ws = torch.empty(int(L.av_lane_workspace_bytes(S, h, w, MS)), dtype=torch.uint8, device=dev)
+    nat.check(L.av_lane_workspace_init(ctx.handle, sh, S, h, w, MS, nat.ptr(ws)))
+    state = torch.zeros(S, 8, dtype=torch.float64, device=dev)
+    poly = torch.zeros(S, 2, 3, dtype=torch.float64, device=dev)
+    pts = torch.zeros(S, 2, 50, 2, dtype=torch.int32, device=dev)
+    info = torch.zeros(S, 8, dtype=torch.int32, device=dev)
+    conf = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+    cfg = nat.LaneCfg(50, 50, 150, MS, 0.7)
+
+    def view(what, dtype, shape):
+        off, nb = C.c_size_t(), C.c_size_t()
+        nat.check(L.av_lane_workspace_view(what, S, h, w, MS, C.byref(off), C.byref(nb)))
+        return ws[off.value:off.value + nb.value].cpu().numpy().view(dtype).reshape(shape)
+
+    def run():
+        nat.check(L.av_lane_detect(ctx.handle, sh, C.byref(cfg), S, h, w, nat.ptr(bgr), None, nat.ptr(ws), nat.ptr(state),
+                                   nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), 0))
+        torch.cuda.synchronize()
+        return view(6, np.int32, (S,)).copy(), view(5, np.int32, (S, MS, 4)).copy(), view(8, np.int32, (S,)).copy()
+
+    want = [LaneRef().detect(f)["segments"] for f in frames]
+    assert all(len(x) > 0 for x in want)
+    n0, s0, p0 = run()
+    assert (p0 == 1).all(), p0                                       # undisturbed: every frame on the sharded kernel
+    monkeypatch.setenv("AVHOT_HOUGH_SPIN", "2000")
+    for victim in (2, 0):
+        monkeypatch.setenv("AVHOT_HOUGH_DROP", str(victim))
+        n, sg, p = run()
+        assert p[victim] == 2 and (np.delete(p, victim) == 1).all(), (victim, p)
+        for s in range(S):
+            assert n[s] == len(want[s]) and np.array_equal(sg[s, :n[s]], want[s]), (victim, s)
+    monkeypatch.delenv("AVHOT_HOUGH_DROP")
+    n, sg, p = run()
+    assert (p == 1).all() and np.array_equal(n, n0)

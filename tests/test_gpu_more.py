@@ -236,7 +236,7 @@ def test_track_table_exchange_single_rank_nccl(torch_gpu):
             for s in range(S):
                 for j, f in enumerate(frames):
                     n = want_n[s, f]
-                    assert hdr["n_rows"][s, j] == n and hdr["stream"][s, j] == s and hdr["frame"][s, j] == 2 * W + f
+                    assert hdr["n_rows"][s, j] == n and hdr["stream"][s, j] == s and hdr["frame"][s, j] == 2 * W + f + 1
                     w = want_rows[s, f][:n]
                     g = rows[s, j]
                     for k in ("id", "x1", "y1", "x2", "y2", "age", "hits", "misses", "cls", "flags"):
@@ -246,7 +246,8 @@ def test_track_table_exchange_single_rank_nccl(torch_gpu):
                     assert np.array_equal(g["vy2"][:n], (2 * w["vy"]).astype(np.int16))
                     assert not g[n:].view(np.uint8).any()
             # kernel == torch statement on the same device tables (whole messages, bytewise)
-            ref = D.pack_wire(loop.snap, loop.snap_n, x.frame_lo, x.n_sel, 0, 2 * W)
+            # (header.frame = the detector's frame count at that frame: 1-based, three windows in)
+            ref = D.pack_wire(loop.snap, loop.snap_n, x.frame_lo, x.n_sel, 0, 0, loop.frame_count)
             assert torch_gpu.equal(ref, x.send[(x.k - 1) & 1])
     finally:
         dist.destroy_process_group()
@@ -269,11 +270,11 @@ def test_track_table_exchange_native_allgather(torch_gpu):
             loop.step()
             got = x.exchange()
             x.synchronize()
-            want = D.pack_wire(loop.snap, loop.snap_n, 0, W, 0, k * W)
+            want = D.pack_wire(loop.snap, loop.snap_n, 0, W, 0, 0, loop.frame_count)
             assert torch_gpu.equal(got, want), k
         hdr, rows = x.latest()
         want_rows, want_n = loop.snapshots()
-        assert np.array_equal(hdr["n_rows"], want_n) and np.array_equal(hdr["frame"][0], 2 * W + np.arange(W))
+        assert np.array_equal(hdr["n_rows"], want_n) and np.array_equal(hdr["frame"][0], 2 * W + 1 + np.arange(W))
     finally:
         x.close()
     assert x.nccl is None

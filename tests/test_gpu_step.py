@@ -61,12 +61,12 @@ def test_fused_step_equals_the_four_stage_launches_bit_for_bit(torch):
         stage.step(graph=False)
         if t % 7 == 0 or t > steps - 4:
             _same(_outputs(fused), _outputs(stage), "step %d" % t)
-            nat.check(nat.lib().av_pack_tracks(stage.ctx.handle, stage._s, S, 1, 64, 0, 1, 40, 0, nat.ptr(stage.snap),
-                                               nat.ptr(stage.snap_n), nat.ptr(ref_wire)))
+            nat.check(nat.lib().av_pack_tracks(stage.ctx.handle, stage._s, S, 1, 64, 0, 1, 40, 1000, nat.ptr(stage.snap),
+                                               nat.ptr(stage.snap_n), nat.ptr(stage.frame_count), nat.ptr(ref_wire)))
             stage.synchronize()
             want = ref_wire.cpu().numpy().copy()
-            # the fused step stamps header.frame = frame0 + the stream's detector frame count (offset + steps so far)
-            want[:, 8:12] = (1000 + np.asarray(offs, np.int32) + t + 1).astype("<i4").view(np.uint8).reshape(S, 4)
+            # both stamp header.frame = frame0 + the stream's detector frame count (offset + steps so far)
+            assert np.array_equal(want[:, 8:12], (1000 + np.asarray(offs, np.int32) + t + 1).astype("<i4").view(np.uint8).reshape(S, 4))
             assert np.array_equal(wire.cpu().numpy(), want), t
     out = _outputs(fused)
     assert out["kf"][3, 45] == 1.0 and out["kf"][0, 45] == 0.0          # the dense filter really ran for stream 3
