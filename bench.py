@@ -231,7 +231,7 @@ def pick_reps(est_step_s, steps, min_s, world):
     """Inner repetitions per reported step so that the timed region lasts >= min_s; every rank uses rank 0's choice."""
     import torch
     import torch.distributed as dist
-    r = max(1, int(min_s / max(est_step_s * steps, 1e-9) + 0.999))
+    r = max(1, int(1.4 * min_s / max(est_step_s * steps, 1e-9) + 0.999))     # (the probe includes a drain: it overestimates)
     if world > 1:
         t = torch.tensor([r], dtype=torch.int64, device="cuda")
         dist.broadcast(t, 0)

@@ -185,6 +185,7 @@ def test_config3_bench_size_all_64_cameras(torch):
     n, box, dconf, cls = (loop.det_n.cpu().numpy(), loop.det_box.cpu().numpy(), loop.det_conf.cpu().numpy(),
                           loop.det_cls.cpu().numpy())
     single = Y.YoloV8n("random:0")
+    worst_fit = 0.0
     for s in range(S):
         assert np.array_equal(frames[s], synthetic_frame(h, w, s, steps - 1)), s
         want = wants[s]
@@ -193,13 +194,18 @@ def test_config3_bench_size_all_64_cameras(torch):
         for side, exp in ((0, want["left"]), (1, want["right"])):
             assert bool(info[s, side]) == (exp is not None), (s, side)
             if exp is not None:
-                np.testing.assert_allclose(poly[s, side], exp[2], rtol=1e-6, atol=1e-6)
+                # the fit after three EMA steps, as a curve: x(y) of device and oracle within 1e-3 px over the ROI's rows (the
+                # coefficients of a near-degenerate fit -- few, short segments -- agree to ~1e-5 relative)
+                yy = np.linspace(0.6 * h, h, 50)
+                worst_fit = max(worst_fit, float(np.abs(np.polyval(poly[s, side], yy) - np.polyval(exp[2], yy)).max()))
+                np.testing.assert_allclose(poly[s, side], exp[2], rtol=1e-4, atol=1e-4)
                 assert conf[s, side] == exp[1]
                 assert np.abs(pts[s, side] - exp[0]).max() <= 1
         sb, sc, sk = single.detect(frames[s])
         assert n[s] == len(sc) > 0, s
         assert np.array_equal(box[s, :n[s]], sb) and np.array_equal(dconf[s, :n[s]], sc) and np.array_equal(cls[s, :n[s]], sk), s
     single.close()
+    assert worst_fit <= 1e-3, worst_fit
     # the frames were sized for the sharded kernel: it is the one that ran, unless a partner did not show up in time
     assert (path == 1).sum() >= S // 2, np.bincount(path, minlength=4)
 
