@@ -26,7 +26,7 @@ constexpr int TW = 128, TH = 32;            // output tile of the pixel kernels
 constexpr int NUMANGLE = 180;
 
 struct LaneWs {                              // offsets (bytes) into the caller's workspace, per launch
-    size_t blur, map, labels, edges, masked, hist, thr, rowcnt, nz, npts, accum, segs, nseg, tedge, total;
+    size_t blur, map, labels, edges, masked, hist, thr, rowcnt, nz, npts, accum, segs, nseg, tedge, rbits, kbits, total;
     int numrho;
 };
 
@@ -53,6 +53,10 @@ __host__ LaneWs lane_layout(int S, int h, int w, int max_segments) {
     // per 16 x 256 hysteresis tile: candidate bits of its top and bottom rows (8 + 8 words) and of its first and last columns
     // (16 + 16 bits), written by the tile pass for the border pass (TE_WORDS words per tile)
     L.tedge = o, o = al256(o + (size_t)S * ((h + 15) / 16) * ((w + 255) / 256) * 20 * 4);
+    // one bit per pixel of the ROI's chunk box: candidates inside the ROI (tile pass -> resolve pass), kept edges (-> compaction);
+    // sized for a box as large as the frame, rows padded to whole 32-bit words
+    L.rbits = o, o = al256(o + (size_t)S * h * (((w + 15) / 16 + 2) / 2) * 4);
+    L.kbits = o, o = al256(o + (size_t)S * h * (((w + 15) / 16 + 2) / 2) * 4);
     L.total = o;
     return L;
 }
@@ -1262,10 +1266,14 @@ __device__ __forceinline__ void ccl_links(unsigned C, unsigned U, unsigned out[4
 // (Four tiles a quarter of the frame apart, so that a workgroup's tiles are not non-empty together: 47 us -- the kernel's time
 // is the non-empty tiles' serial LDS work, not its loads.)
 constexpr int CT_STACK = 1;
+struct BitBox {                    // the ROI's chunk box in the bit maps: first chunk column / row, chunks per row, rows, 32-bit words per row
+    int bx0, by0, bcw, bch, pw;
+};
 template <bool NM>
 __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict__ map_all, int h, int w,
                                                        const double* __restrict__ thr, unsigned* __restrict__ labels_all,
-                                                       unsigned* __restrict__ tedge_all) {
+                                                       unsigned* __restrict__ tedge_all, const int* __restrict__ roi_tab,
+                                                       uint16_t* __restrict__ rbits_all, BitBox bb) {
     __shared__ unsigned lab[CT_PX];               // local label: pixel index inside the tile (row * 256 + column), bit 31 = weak
     __shared__ unsigned cm[CT_NCH];               // per 16-pixel chunk: candidate bits | strong bits << 16
     static_assert(CT_NCH == 256, "one chunk per thread and tile");
@@ -1290,6 +1298,15 @@ __global__ void __launch_bounds__(256) ccl_tile_kernel(const uint8_t* __restrict
         if (y0 >= h) break;
         unsigned cand, strong;
         map_bits<NM>(vq[t], lo2, hi2, cand, strong);
+        if (roi_tab) {                 // the chunk's candidates inside the ROI, one bit per pixel, for the resolve pass (every chunk of
+            const int yy = y0 + r, cx = x >> 4;      // the box writes its half-word, also those of tiles without any candidate)
+            if (yy >= bb.by0 && yy < bb.by0 + bb.bch && cx >= bb.bx0 && cx < bb.bx0 + bb.bcw) {
+                const int lo = roi_tab[2 * yy] - x, hi = roi_tab[2 * yy + 1] - x;        // ROI columns [xl, xr] relative to the chunk
+                unsigned cm16 = 0;
+                if (hi >= 0 && lo <= 15 && lo <= hi) cm16 = (0xFFFFu >> (15 - (hi > 15 ? 15 : hi))) & (0xFFFFu << (lo < 0 ? 0 : lo));
+                rbits_all[((size_t)s * bb.bch + (yy - bb.by0)) * (2 * bb.pw) + (cx - bb.bx0)] = (uint16_t)(cand & cm16);
+            }
+        }
         unsigned* te = tedge_all + (((size_t)s * gridDim.y * CT_STACK + (y0 / CT_R)) * gridDim.x + blockIdx.x) * TE_WORDS;
         if (__syncthreads_or(cand != 0 ? 1 : 0) == 0) {               // no candidate in the tile (also fences the previous tile's reads)
             if (tid < 18) te[tid] = 0;
@@ -1473,6 +1490,33 @@ __global__ void __launch_bounds__(256) finalize_fast(const uint8_t* __restrict__
     }
 }
 
+// The same verdict from the tile pass's ROI candidate bits (production shape: default ROI, no debug edge map): a thread per 32-bit
+// word of the box.  Neither the map nor the masked byte map is touched -- the resolve pass used to re-read 1 B/px of the box and
+// write 1 B/px of masked map that the compaction read back; now both passes move one BIT per box pixel.  Adjacent candidates
+// share their component: one find per run of set bits.
+__global__ void __launch_bounds__(256) resolve_bits_kernel(int h, int w, unsigned* __restrict__ labels_all,
+                                                          const unsigned* __restrict__ rbits_all, unsigned* __restrict__ kbits_all,
+                                                          int* __restrict__ rowcnt, BitBox bb) {
+    const int s = blockIdx.y;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x, total = (unsigned)(bb.bch * bb.pw);
+    if (i >= total) return;
+    const size_t wi = (size_t)s * total + i;
+    unsigned rest = rbits_all[wi], keep = 0;
+    if (rest) {
+        unsigned* lab = labels_all + (size_t)s * h * w;
+        const unsigned row = i / (unsigned)bb.pw, wx = i - row * (unsigned)bb.pw;
+        const int y = bb.by0 + (int)row, xw = bb.bx0 * 16 + 32 * (int)wx;
+        while (rest) {
+            const int a = __ffs((int)rest) - 1;
+            const unsigned run = rest & ~(rest + (1u << a));
+            rest &= ~run;
+            if (!(uf_find(lab, (unsigned)(y * w + xw + a)) >> 31)) keep |= run;
+        }
+        if (keep) atomicAdd(&rowcnt[(size_t)s * h + y], __popc(keep));
+    }
+    kbits_all[wi] = keep;
+}
+
 // ---- L4a: row-major list of edge points -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict__ masked, int h, int w,
                                                       const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
@@ -1515,7 +1559,10 @@ __global__ void __launch_bounds__(256) compact_kernel(const uint8_t* __restrict_
 constexpr int CB_ROWS = 8192;                   // rows the scan holds (the box is 288 rows for the default ROI at 720p)
 __global__ void __launch_bounds__(1024) compact_box_kernel(const uint8_t* __restrict__ masked, int h, int w,
                                                            const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
-                                                           int* __restrict__ npts, int bx0, int by0, int bcw, int bch) {
+                                                           int* __restrict__ npts, int bx0, int by0, int bcw, int bch,
+                                                           const unsigned* __restrict__ kbits_all, int pw) {
+    // kbits_all: the kept-edge bit map of the box (resolve_bits_kernel), pw words per row -- a lane per 32-pixel word; else the
+    // masked byte map, a lane per 16-pixel chunk
     extern __shared__ int cb_base[];                        // [bch] exclusive prefix of the box rows' counts
     __shared__ int wtot[16];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1554,6 +1601,30 @@ __global__ void __launch_bounds__(1024) compact_box_kernel(const uint8_t* __rest
         if (rc[i] == 0) continue;                           // wave-uniform
         const int y = by0 + i;
         int base = cb_base[i];
+        if (kbits_all) {
+            const unsigned* krow = kbits_all + ((size_t)s * bch + i) * pw;
+            for (int c0 = 0; c0 < pw; c0 += 64) {
+                const int c = c0 + lane;
+                unsigned bits = c < pw ? krow[c] : 0u;
+                const int n = __popc(bits);
+                int pre = n;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(pre, d, 64);
+                    if (lane >= d) pre += t;
+                }
+                const int tot = __shfl(pre, 63, 64);
+                int o = base + pre - n;
+                const unsigned xb = (unsigned)(bx0 * 16 + c * 32);
+                while (bits) {
+                    const int k = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    out[o++] = (xb + (unsigned)k) | ((unsigned)y << 16);
+                }
+                base += tot;
+            }
+            continue;
+        }
         const uint8_t* row = masked + ((size_t)s * h + y) * w + (size_t)bx0 * 16;
         uint4 vnext = make_uint4(0, 0, 0, 0);
         if (lane < bcw) vnext = *reinterpret_cast<const uint4*>(row + (size_t)lane * 16);
@@ -1602,7 +1673,7 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
                                                      const int* __restrict__ npts, int* __restrict__ accum_all,
                                                      const float* __restrict__ trig, int* __restrict__ segs,
                                                      int* __restrict__ nseg, const int* __restrict__ fallback,
-                                                     int* __restrict__ path) {
+                                                     int* __restrict__ path, int rebuild_mask) {
     __shared__ int w_key[3];
     __shared__ int sh_pt[2];
     __shared__ unsigned long long flags[64];           // mask bits of 4096 walk steps
@@ -1614,6 +1685,15 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
     unsigned* nz = nz_all + (size_t)s * h * w;
     int* accum = accum_all + (size_t)s * NUMANGLE * numrho;
     for (size_t q = tid; q < (size_t)NUMANGLE * numrho; q += 192) accum[q] = 0;
+    if (rebuild_mask) {
+        // the bit-map resolve pass writes no masked byte map (only this kernel reads one): made here from the point list, after
+        // clearing what an earlier frame's walk left behind (w % 16 == 0 on that path)
+        for (size_t q = (size_t)tid * 16; q < (size_t)h * w; q += 192 * 16) *reinterpret_cast<uint4*>(mask + q) = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        const int total = npts[s];
+        for (int q = tid; q < total; q += 192) mask[(size_t)(nz[q] >> 16) * w + (nz[q] & 0xffffu)] = 255;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     const bool th_on = tid < NUMANGLE;
@@ -2664,6 +2744,8 @@ __global__ void __launch_bounds__(64) lane_fit_kernel(int S, int h, int w, int m
 
 struct LaneCtx {
     float* d_trig = nullptr;
+    int* d_roi = nullptr;           // default trapezoid's [xl, xr] per row for frames of roi_h x roi_w (the bit-map resolve path)
+    int roi_h = 0, roi_w = 0;
 };
 
 }  // namespace
@@ -2674,6 +2756,7 @@ int av_lane_ctx_free(av_ctx* ctx) {
     if (ctx && ctx->lane) {
         LaneCtx* lc = (LaneCtx*)ctx->lane;
         if (lc->d_trig) (void)hipFree(lc->d_trig);
+        if (lc->d_roi) (void)hipFree(lc->d_roi);
         delete lc;
         ctx->lane = nullptr;
     }
@@ -2699,6 +2782,8 @@ int av_lane_workspace_view(int what, int n_streams, int h, int w, int max_segmen
         case 6: *offset = L.nseg, *bytes = (size_t)n_streams * 4; break;
         case 7: *offset = L.accum, *bytes = (size_t)n_streams * NUMANGLE * L.numrho * 4; break;
         case 8: *offset = L.rowcnt + (size_t)n_streams * 4, *bytes = (size_t)n_streams * 4; break;     // Hough kernel taken per frame
+        case 9: *offset = L.nz, *bytes = px * 4; break;                      // point lists: frame s at [s * h * w], x | y << 16, row-major
+        case 10: *offset = L.npts, *bytes = (size_t)n_streams * 4; break;
         default: av_set_error("av_lane_workspace_view: unknown view %d", what); return AV_EINVAL;
     }
     return AV_OK;
@@ -2751,6 +2836,9 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     int* segs = (int*)(ws + L.segs);
     int* nseg = (int*)(ws + L.nseg);
     unsigned* tedge = (unsigned*)(ws + L.tedge);
+    unsigned* rbits = (unsigned*)(ws + L.rbits);
+    unsigned* kbits = (unsigned*)(ws + L.kbits);
+    bool bitpath = false;            // this call resolved the ROI through the bit maps (no masked byte map written)
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
     const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0 &&
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
@@ -2816,10 +2904,37 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         roi.x0 = (int)(w * 0.1), roi.x1 = (int)(w * 0.4), roi.x2 = (int)(w * 0.6), roi.x3 = (int)(w * 0.9);
         roi.yt = (int)(h * 0.6);                                       // lane_detector.py:55-60
         int cbox[4] = {0, 0, w >> 4, h}, cbox_rows = h;               // chunk box of the resolve / compaction passes
+        BitBox bb{0, 0, 0, 0, 0};
         if (fastp) {
+            // default ROI, no debug edge map: the tile pass leaves the ROI's candidates as one bit per pixel of the ROI's chunk box and
+            // the resolve / compaction passes work on bit maps (AVHOT_LANE_BYTE_RESOLVE=1: the byte-map passes of round 3)
+            bitpath = !(stages & 1) && !roi_rows && roi.yt < h && (h - roi.yt) <= CB_ROWS && !getenv("AVHOT_LANE_BYTE_RESOLVE");
+            if (bitpath) {
+                if (!lc->d_roi || lc->roi_h != h || lc->roi_w != w) {
+                    std::vector<int> tab(2 * (size_t)h);
+                    for (int y = 0; y < h; ++y) {
+                        int xl = 1, xr = 0;
+                        if (y >= roi.yt) {                             // roi_bounds' arithmetic
+                            const long long den = h - roi.yt, t = h - y;
+                            xl = (int)((2 * (roi.x0 * den + (long long)(roi.x1 - roi.x0) * t) + den) / (2 * den));
+                            xr = (int)((2 * (roi.x3 * den + (long long)(roi.x2 - roi.x3) * t) + den) / (2 * den));
+                        }
+                        tab[2 * y] = xl, tab[2 * y + 1] = xr;
+                    }
+                    if (lc->d_roi) AV_HIP(hipFree(lc->d_roi));
+                    lc->d_roi = nullptr;
+                    AV_HIP(hipMalloc(&lc->d_roi, tab.size() * sizeof(int)));
+                    AV_HIP(hipMemcpy(lc->d_roi, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                    lc->roi_h = h, lc->roi_w = w;
+                }
+                bb.by0 = roi.yt, bb.bch = h - roi.yt;
+                bb.bx0 = roi.x0 >> 4, bb.bcw = (((roi.x3 < w ? roi.x3 : w - 1) >> 4) - bb.bx0) + 1;
+                bb.pw = (bb.bcw + 1) / 2;
+            }
             const dim3 tgrid((w + CT_C - 1) / CT_C, ((h + CT_R - 1) / CT_R + CT_STACK - 1) / CT_STACK, n_streams);
-            if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge);
-            else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge);
+            const int* rt = bitpath ? lc->d_roi : nullptr;
+            if (fused) hipLaunchKernelGGL(ccl_tile_kernel<true>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge, rt, (uint16_t*)rbits, bb);
+            else hipLaunchKernelGGL(ccl_tile_kernel<false>, tgrid, dim3(256), 0, st, map, h, w, thr, labels, tedge, rt, (uint16_t*)rbits, bb);
             const int nbh = (h - 1) / CT_R, nbv = (w - 1) / CT_C, span = (w > h ? w : h);
             if (nbh + nbv > 0) {
                 const dim3 bgrid((span + 255) / 256, nbh + nbv, n_streams);
@@ -2836,7 +2951,10 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
             cbox[0] = bx0, cbox[1] = by0, cbox[2] = bcw, cbox[3] = bch, cbox_rows = bch;
             const unsigned fchunks = (unsigned)bch * (unsigned)bcw;
             const dim3 ngrid((fchunks + 256 * FCK - 1) / (256 * FCK), n_streams);
-            if (fused)
+            if (bitpath)
+                hipLaunchKernelGGL(resolve_bits_kernel, dim3(((unsigned)(bb.bch * bb.pw) + 255) / 256, n_streams), dim3(256), 0, st, h, w,
+                                   labels, rbits, kbits, rowcnt, bb);
+            else if (fused)
                 hipLaunchKernelGGL(finalize_fast<true>, ngrid, dim3(256), 0, st, map, h, w, thr, labels, roi, roi_rows,
                                    (stages & 1) ? edges : nullptr, masked, rowcnt, bx0, by0, bcw, bch);
             else
@@ -2851,7 +2969,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         AV_LAUNCH_CHECK();
         if (fastp && cbox_rows <= CB_ROWS)
             hipLaunchKernelGGL(compact_box_kernel, dim3(n_streams, 4), dim3(1024), (size_t)cbox_rows * sizeof(int), st, masked, h, w,
-                               rowcnt, nz, npts, cbox[0], cbox[1], cbox[2], cbox[3]);
+                               rowcnt, nz, npts, cbox[0], cbox[1], cbox[2], cbox[3], bitpath ? kbits : nullptr, bb.pw);
         else hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
         AV_LAUNCH_CHECK();
     }
@@ -2863,6 +2981,9 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
+    // Hough-only calls (stage bit 4) follow a pixel-stage call of the same shape: the same path decision
+    const bool rebuild = (stages & 16) ? (fastp && !roi_rows && (int)(h * 0.6) < h && (h - (int)(h * 0.6)) <= CB_ROWS && !getenv("AVHOT_LANE_BYTE_RESOLVE"))
+                                       : bitpath;
     int* fb = rowcnt;       // the per-row counters are dead after compaction: their first n_streams words are the fallback flags,
     int* hpath = rowcnt + n_streams;   // the next n_streams say which kernel made a frame's segments (1 shard, 2 fast, 3 generic)
     const bool use_fast = !(stages & 8);
@@ -2887,7 +3008,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         AV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
-                       lc->d_trig, segs, nseg, use_fast ? fb : nullptr, hpath);
+                       lc->d_trig, segs, nseg, use_fast ? fb : nullptr, hpath, rebuild ? 1 : 0);
     AV_LAUNCH_CHECK();
     hipLaunchKernelGGL(lane_fit_kernel, dim3(n_streams * 2), dim3(64), 0, st, n_streams, h, w,
                        cfg->max_segments, cfg->smoothing_factor, segs, nseg, lane_state, poly, pts, info, conf, thr, npts);

@@ -48,6 +48,25 @@ def test_pixel_stages_bit_exact(LaneDetector, name, frame):
     assert np.array_equal(det._view(3, np.uint8, (h, w)), want["masked"])
 
 
+@pytest.mark.parametrize("name,frame", _frames(), ids=[n for n, _ in _frames()])
+def test_production_point_list_is_the_oracles_roi_edges_in_row_major_order(LaneDetector, name, frame):
+    """The production shape of the pixel stages (default ROI, no debug edge map; widths divisible by 16 take the bit-map resolve +
+    compaction passes: ROI candidate bits from the tile pass, kept bits, point list -- no masked byte map is written) must leave
+    exactly the list cv::HoughLinesP would collect from the oracle's ROI-masked edge map: every non-zero pixel, row-major.  Run
+    twice on the same detector: nothing in the workspace may survive from the first frame (bit maps, labels, counters)."""
+    from oracle.lane_ref import LaneRef
+    h, w = frame.shape[:2]
+    det = LaneDetector()
+    for fr in (frame[::-1].copy(), frame):                 # a different frame first
+        want = LaneRef().stages(fr)
+        det._run(fr, stages=2)                             # pixel stages only, production shape
+        ys, xs = np.nonzero(want["masked"])
+        n = int(det._view(10, np.int32, (1,))[0])
+        assert n == len(ys)
+        got = det._view(9, np.uint32, (h * w,))[:n]
+        assert np.array_equal(got, (xs.astype(np.uint32) | (ys.astype(np.uint32) << 16)))
+
+
 @pytest.mark.parametrize("name,frame", _frames()[:3], ids=[n for n, _ in _frames()[:3]])
 def test_hough_segments_and_fit(LaneDetector, name, frame):
     from oracle.lane_ref import LaneRef
@@ -165,11 +184,15 @@ def test_batched_frames_take_all_three_hough_paths(LaneDetector):
 
     refs = [LaneRef() for _ in range(S)]
     npts = []
-    for rep in range(3):
+    for rep in range(4):
+        # reps 0-2: debug shape (stage bit 0: pre-ROI edge map kept, byte-map resolve); rep 3: the production shape (bit-map resolve,
+        # no masked byte map -- the generic Hough kernel rebuilds its mask from the point list), EMA state carried on
         nat.check(L.av_lane_detect(ctx.handle, sh, C.byref(cfg), S, h, w, nat.ptr(bgr), None, nat.ptr(ws), nat.ptr(state),
-                                   nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), 1))
+                                   nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), 1 if rep < 3 else 0))
         torch.cuda.synchronize()
         edges = view(2, np.uint8, (S, h, w))
+        if rep == 3:
+            assert sorted(set(view(8, np.int32, (S,)).tolist())) == [1, 2, 3]        # all three Hough kernels, production shape
         segs, nseg = view(5, np.int32, (S, MS, 4)), view(6, np.int32, (S,))
         inf, po, pt, cf = info.cpu().numpy(), poly.cpu().numpy(), pts.cpu().numpy(), conf.cpu().numpy()
         for s in range(S):
