@@ -173,6 +173,22 @@ def load_params(model_path):
     return params_from_state_dict(_load_checkpoint(model_path))
 
 
+class _OwnStream:
+    """A Dev with a stream of its own (stream capture needs a non-default stream; the per-frame detector call keeps its upload,
+    its graph replay and its wait on it)."""
+
+    def __init__(self, dev):
+        self.index, self.device, self.ctx, self.lib = dev.index, dev.device, dev.ctx, dev.lib
+        self._stream = torch.cuda.Stream(device=dev.device)
+
+    @property
+    def stream(self):
+        return nat.stream_handle(self._stream)
+
+    def sync(self):
+        self._stream.synchronize()
+
+
 class YoloV8n:
     def __init__(self, model_path="random", device=0, batch=1, keep_logits=False):
         """keep_logits: test hook -- the head also writes its float32 logits (tensor ids 100-105) and the stand-alone decode
@@ -190,6 +206,13 @@ class YoloV8n:
         self._shape = None
         self._io_in = self._io_out = None      # per-frame call: pinned upload buffer, host-mapped result buffer
         self._io_shape = None
+        # per-frame call (batch 1): the whole forward -- ~56 launches on two lanes -- is captured into ONE hipGraph after the first
+        # eager call and replayed from then on (demo.py:107 calls the detector once per frame: launch overhead, not kernel time,
+        # is what a single 384x640 image costs).  AVHOT_YOLO_NO_GRAPH=1 keeps the eager launches.
+        self._gdev = None
+        self._graphs = {}                      # (conf, iou) -> graph id, for the current shape
+        self._warm = set()
+        self.use_graph = os.environ.get("AVHOT_YOLO_NO_GRAPH", "0") != "1"
 
     def _prepare(self, h, w):
         if self._shape == (h, w):
@@ -233,7 +256,9 @@ class YoloV8n:
             self.forward_device(self._frames, conf, iou)
             n = int(self._n[0].item())
             return (self._box[0, :n].cpu().numpy(), self._conf[0, :n].cpu().numpy(), self._cls[0, :n].cpu().numpy())
-        d = self._dev
+        if self._gdev is None:
+            self._gdev = _OwnStream(self._dev)
+        d = self._gdev
         if self._io_shape != (h, w):
             from .._dev import Packed
             for io in (self._io_in, self._io_out):
@@ -245,8 +270,26 @@ class YoloV8n:
             self._io_shape = (h, w)
         self._io_in.upload_from("frame", frame)
         o = self._io_out
-        nat.check(d.lib.av_yolo_forward(self._h, d.stream, self._io_in.ptr("frame"), conf, iou, MAX_DET, o.ptr("n"), o.ptr("box"),
-                                        o.ptr("conf"), o.ptr("cls")))
+
+        def enqueue():
+            nat.check(d.lib.av_yolo_forward(self._h, d.stream, self._io_in.ptr("frame"), conf, iou, MAX_DET, o.ptr("n"), o.ptr("box"),
+                                            o.ptr("conf"), o.ptr("cls")))
+        key = (float(conf), float(iou))
+        gid = self._graphs.get(key)
+        if gid is None and self.use_graph and key in self._warm and not self.keep_logits:
+            # second call with these thresholds: every one-time host action of the forward (symbol uploads, attributes) is behind us
+            g = C.c_int(-1)
+            nat.check(d.lib.av_graph_begin(d.ctx.handle, d.stream))
+            try:
+                enqueue()
+            finally:
+                nat.check(d.lib.av_graph_end(d.ctx.handle, d.stream, C.byref(g)))
+            gid = self._graphs[key] = g.value
+        if gid is not None:
+            nat.check(d.lib.av_graph_launch(d.ctx.handle, gid, d.stream))
+        else:
+            enqueue()
+            self._warm.add(key)
         o.download()
         n = int(o.h["n"][0])
         return o.h["box"][:n].copy(), o.h["conf"][:n].copy(), o.h["cls"][:n].copy()
@@ -280,6 +323,11 @@ class YoloV8n:
     def close(self):
         if self._h is not None:
             self._dev.sync()
+            if self._gdev is not None:
+                self._gdev.sync()
+            for gid in self._graphs.values():           # the graphs hold this handle's buffers and kernel arguments
+                self._dev.lib.av_graph_destroy(self._dev.ctx.handle, gid)
+            self._graphs, self._warm = {}, set()
             self._dev.lib.av_yolo_destroy(self._h)
             self._h = None
         for io in (getattr(self, "_io_in", None), getattr(self, "_io_out", None)):

@@ -513,3 +513,34 @@ def test_gemm_form_1x1_layers_equal_weight_stationary_kernels(setup, monkeypatch
     for k in range(6, 9):
         assert np.array_equal(base[k], gemm[k])
     m.close()
+
+
+def test_per_frame_call_as_one_graph_equals_the_eager_launches(setup, monkeypatch):
+    """ObjectDetector(mode="yolo").detect(frame) -- one frame per call, demo.py:107 -- replays the whole forward (about 56 launches
+    on two lanes + sort + NMS) as ONE captured hipGraph from its third call on.  Same kernels, same arguments: the detections of
+    every frame must be those of the eager launches bit for bit, also when the thresholds change (a second graph) and when the
+    frame size changes (graphs dropped with the handle)."""
+    Y, R, frame, feats, _, _ = setup
+    from oracle.lane_ref import synthetic_frame
+    frames = [frame, synthetic_frame(720, 1280, 3, 9), np.random.RandomState(11).randint(0, 256, (720, 1280, 3)).astype(np.uint8),
+              synthetic_frame(720, 1280, 6, 2)]
+    monkeypatch.setenv("AVHOT_YOLO_NO_GRAPH", "1")
+    eager = Y.YoloV8n("random:0")
+    monkeypatch.delenv("AVHOT_YOLO_NO_GRAPH")
+    graph = Y.YoloV8n("random:0")
+    assert graph.use_graph and not eager.use_graph
+    for rep in range(3):
+        for i, fr in enumerate(frames):
+            a, b = eager.detect(fr), graph.detect(fr)
+            assert len(a[1]) > 0 and all(np.array_equal(x, y) for x, y in zip(a, b)), (rep, i)
+    assert len(graph._graphs) == 1 and not eager._graphs
+    a, b = eager.detect(frames[1], conf=0.3, iou=0.5), None
+    for _ in range(3):
+        b = graph.detect(frames[1], conf=0.3, iou=0.5)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(graph._graphs) == 2
+    small = synthetic_frame(480, 640, 1, 1)
+    for _ in range(3):
+        a, b = eager.detect(small), graph.detect(small)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert len(graph._graphs) == 1                       # the 720p graphs went with their handle
+    eager.close(), graph.close()
