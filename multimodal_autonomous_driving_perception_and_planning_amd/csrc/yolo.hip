@@ -1935,13 +1935,6 @@ struct Yolo {
     // class convolution of level dec_level (its epilogue can do the decode)
     hipStream_t side = nullptr;          // the Detect head's class branches run beside its box branches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // latency mode (a few images per forward: the per-frame class call): every Detect branch on a lane of its own, forked from the
-    // caller's stream the moment its level's feature map exists (P3 after layer 15, P4 after 18, P5 after 21) -- six short chains
-    // beside the rest of the neck instead of two chains of nine launches behind it
-    hipStream_t hl[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t hl_fork[3] = {nullptr, nullptr, nullptr}, hl_join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int lvl_ready[3] = {-1, -1, -1};     // index of the op that completes level i's feature map
-    int lvl_head[3] = {-1, -1, -1};      // first of level i's six head ops (box x 3, class x 3)
     // deferred tail (throughput mode): decode + sort + NMS of forward k run on their own stream beside the convolutions
     // of forward k+1 -- they occupy one workgroup per image and ~0.25 ms, the latency-bound end of an otherwise
     // chip-wide chain.  Outputs are complete after av_yolo_join_tail().
@@ -2309,12 +2302,6 @@ int av_yolo_destroy(av_yolo* h) {
     if (h->y.ev_tail) (void)hipEventDestroy(h->y.ev_tail);
     if (h->y.ev_fork) (void)hipEventDestroy(h->y.ev_fork);
     if (h->y.ev_join) (void)hipEventDestroy(h->y.ev_join);
-    for (int i = 0; i < 6; ++i) {
-        if (h->y.hl[i]) (void)hipStreamDestroy(h->y.hl[i]);
-        if (h->y.hl_join[i]) (void)hipEventDestroy(h->y.hl_join[i]);
-    }
-    for (int i = 0; i < 3; ++i)
-        if (h->y.hl_fork[i]) (void)hipEventDestroy(h->y.hl_fork[i]);
     delete h;
     return AV_OK;
 }
@@ -2364,13 +2351,10 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     add_simple(y, 2, Slice{cat17, 64, 128}, Slice{cat14, 0, 128}, H / 16, W / 16, 128);            // 13 upsample -> cat14[0:128]
     y.ops.back().vcat = (int)y.ops.size();                                                          // (layer 15's cv1)
     ok = ok && add_c2f(y, Slice{cat14, 0, 192}, Slice{p3, 0, 64}, 1, false);                       // 15
-    y.lvl_ready[0] = (int)y.ops.size() - 1;
     CV(Slice{p3, 0, 64}, Slice{cat17, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                   // 16 -> cat17[0:64]
     ok = ok && add_c2f(y, Slice{cat17, 0, 192}, Slice{p4, 0, 128}, 1, false);                      // 18
-    y.lvl_ready[1] = (int)y.ops.size() - 1;
     CV(Slice{p4, 0, 128}, Slice{cat20, 0, 128}, 3, 2, true, nullptr, 0, nullptr);                 // 19 -> cat20[0:128]
     ok = ok && add_c2f(y, Slice{cat20, 0, 384}, Slice{p5, 0, 256}, 1, false);                      // 21
-    y.lvl_ready[2] = (int)y.ops.size() - 1;
     const int pl[3] = {p3, p4, p5}, pc[3] = {64, 128, 256}, dv[3] = {8, 16, 32};
     y.A = 0;
     for (int i = 0; i < 3 && ok; ++i) {
@@ -2381,7 +2365,6 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         ok = ok && dev_alloc(y, (void**)&y.head_cls[i], (size_t)batch * hh * ww * NC * 4);
         if (!ok) break;
         if (i == 0) y.head_begin = (int)y.ops.size();
-        y.lvl_head[i] = (int)y.ops.size();
         CV(Slice{pl[i], 0, pc[i]}, Slice{ba, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{ba, 0, 64}, Slice{bb, 0, 64}, 3, 1, true, nullptr, 0, nullptr);
         CV(Slice{bb, 0, 64}, Slice{-1, 0, 64}, 1, 1, false, y.head_box[i], 64, nullptr);
@@ -2414,13 +2397,6 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
         AV_HIP(hipStreamCreateWithFlags(&y.side, hipStreamNonBlocking));
         AV_HIP(hipEventCreateWithFlags(&y.ev_fork, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&y.ev_join, hipEventDisableTiming));
-        if (batch <= 4) {
-            for (int i = 0; i < 6; ++i) {
-                AV_HIP(hipStreamCreateWithFlags(&y.hl[i], hipStreamNonBlocking));
-                AV_HIP(hipEventCreateWithFlags(&y.hl_join[i], hipEventDisableTiming));
-            }
-            for (int i = 0; i < 3; ++i) AV_HIP(hipEventCreateWithFlags(&y.hl_fork[i], hipEventDisableTiming));
-        }
     }
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lds_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
@@ -2544,36 +2520,11 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     // (Walking the chain with 2 or 4 sub-batches of the frames on as many streams was measured, to let one group's per-launch
     // latency hide behind another's work: 1.78 -> 1.80 / 1.99 ms at 64 frames -- every launch already occupies the whole chip,
     // so the groups only queue behind each other; dropped)
-    // six head lanes (latency mode): not with a deferred tail (the head rewrites the candidates the previous forward's tail reads)
-    const bool lanes6 = y.hl[0] && !y.defer_tail && !y.tail_pending && y.head_begin >= 0 && y.lvl_head[2] + 6 == (int)y.ops.size() &&
-                        !getenv("AVHOT_YOLO_HEAD_LANES2");
-    int next_fork = 0;
-    auto fork_levels = [&](int done_upto) -> int {         // levels whose feature map is complete once op `done_upto` has been enqueued
-        while (next_fork < 3 && y.lvl_ready[next_fork] <= done_upto) {
-            const int lv = next_fork++;
-            AV_HIP(hipEventRecord(y.hl_fork[lv], st_main));
-            for (int br = 0; br < 2; ++br) {
-                const hipStream_t hs = y.hl[2 * lv + br];
-                AV_HIP(hipStreamWaitEvent(hs, y.hl_fork[lv], 0));
-                for (int q = 0; q < 3; ++q) {
-                    const int rc = launch_op(y, y.ops[y.lvl_head[lv] + 3 * br + q], hs, B, force_direct);
-                    if (rc != AV_OK) return rc;
-                }
-                AV_HIP(hipEventRecord(y.hl_join[2 * lv + br], hs));
-            }
-        }
-        return AV_OK;
-    };
     for (size_t oi = first_op; oi < y.ops.size(); ++oi) {
-        if (lanes6) {
-            const int rc = fork_levels((int)oi - 1);       // (fused blocks advance oi past their last op: everything below oi is enqueued)
-            if (rc != AV_OK) return rc;
-            if ((int)oi >= y.head_begin) break;
-        }
         const Yolo::Op& op = y.ops[oi];
         if ((int)oi == y.head_begin && y.tail_pending)     // the previous forward's sort + NMS must be done with the candidates the head rewrites
             AV_HIP(hipStreamWaitEvent(st_main, y.ev_tail, 0));
-        if (y.side && !lanes6 && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
+        if (y.side && (int)oi == y.head_begin) {           // backbone + neck done on the caller's stream: open the side lane
             AV_HIP(hipEventRecord(y.ev_fork, st_main));
             AV_HIP(hipStreamWaitEvent(y.side, y.ev_fork, 0));
         }
@@ -2685,11 +2636,6 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         const int rc = launch_op(y, op, (y.side && op.lane) ? y.side : st_main, B, force_direct);
         if (rc != AV_OK) return rc;
     }
-    if (lanes6) {
-        const int rc = fork_levels((int)y.ops.size());
-        if (rc != AV_OK) return rc;
-        for (int i = 0; i < 6; ++i) AV_HIP(hipStreamWaitEvent(st_main, y.hl_join[i], 0));      // the sort reads every branch's candidates
-    } else
     if (y.side && y.head_begin >= 0) {                     // the decode reads both branches
         AV_HIP(hipEventRecord(y.ev_join, y.side));
         AV_HIP(hipStreamWaitEvent(st_main, y.ev_join, 0));
