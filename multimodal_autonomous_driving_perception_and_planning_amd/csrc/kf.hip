@@ -158,10 +158,7 @@ constexpr int RAW = 12;   // per frame: px py vx vy vxp vyp Ppos_x Ppos_y Pvel_x
 // kernel of step.hip in the first wave of a planner workgroup).  Returns false when the stream is flagged for the dense filter.
 __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames, const double* __restrict__ z,
                                              const uint8_t* __restrict__ mode, double* __restrict__ kf_state,
-                                             double* __restrict__ out_state, double* __restrict__ plan_state, const int s, const int lane,
-                                             double* plan_lds = nullptr) {
-    // plan_lds (the one-launch step, one frame): the planner's start state also goes to these four LDS doubles, so that the
-    // planner behind it needs no round trip through memory
+                                             double* __restrict__ out_state, double* __restrict__ plan_state, const int s, const int lane) {
     __shared__ __attribute__((aligned(16))) double zl[KF_BATCH][4];
     __shared__ __attribute__((aligned(16))) double raw[KF_BATCH][RAW];
     __shared__ int ml[KF_BATCH];
@@ -313,7 +310,6 @@ __device__ __forceinline__ bool kf_axis_body(const av_kf_cfg& cfg, int n_frames,
             dst[3] = make_double2(acc, yaw), dst[4] = make_double2(w[10], sqrt(w[6] + w[7]));
             dst[5] = make_double2(sqrt(w[8] + w[9]), 0.0);
             if (plan_state) reinterpret_cast<double4*>(plan_state)[sf0 + lane] = make_double4(px, py, heading, speed);
-            if (plan_lds && lane == nb - 1) plan_lds[0] = px, plan_lds[1] = py, plan_lds[2] = heading, plan_lds[3] = speed;
         }
         carry_h = __shfl(heading, nb - 1, 64);
         carry_sp = __shfl(speed, nb - 1, 64);

@@ -101,10 +101,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int G, int NW>
 __device__ __forceinline__ void plan_block(const PlanParams& p, int f0, int n_states, const double* __restrict__ state,
                                            const double* __restrict__ ref, int n_ref, const double* __restrict__ obs, int n_obs,
-                                           double* __restrict__ wp, double* __restrict__ cost, int32_t* __restrict__ order, double* sm,
-                                           const double* state_lds = nullptr) {
-    // state_lds (G = 1): the start state's four doubles in LDS instead of state[f0] in memory (same values)
-    if (G == 1 && state_lds) state = state_lds - (size_t)f0 * 4;
+                                           double* __restrict__ wp, double* __restrict__ cost, int32_t* __restrict__ order, double* sm) {
     const int n = p.n, C = p.C;
     double* vs = sm;                                   // [G][3][n][2]  (v, s)
     double* base = vs + (size_t)G * 3 * n * 2;         // [G][3][3]     S_v, S_a, running(S_v then acc terms)

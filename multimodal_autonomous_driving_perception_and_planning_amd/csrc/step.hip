@@ -57,33 +57,12 @@ __global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
         }
     } else {
         const int s = blockIdx.x - a.S;
-        __shared__ __attribute__((aligned(16))) double sh_plan[4];
-        __shared__ int sh_dense;
         if (tid < 64) {
-            const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid, sh_plan);
-            if (tid == 0) sh_dense = separable ? 0 : 1;
+            const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid);
             if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);   // (LDS form: kf_dense.inc)
-        } else {
-            // the seven waves that wait for the Kalman step warm the caches with the planner's per-waypoint tables (their first
-            // touch was ~1 us of L2 / memory latency in front of phase 1)
-            const int l = tid & 63;
-            if (l < a.pp.n) {
-                const double w0 = a.pp.alpha[l], w1 = a.pp.dtd[l], w2 = a.pp.q[l], w3 = a.pp.t[l];
-                asm volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(w3));
-            }
-            if (l < a.pp.n_lat) {
-                const double w4 = a.pp.lat[l];
-                asm volatile("" :: "v"(w4));
-            }
         }
-        // The planner's start state goes through LDS (kf_axis_body wrote it to sh_plan as well as to plan_state[s]): an LDS-only barrier,
-        // where __syncthreads() would wait for the Kalman step's stores to reach memory (vmcnt(0)) -- a memory round trip in the middle
-        // of the step's critical path.  A stream on the dense filter (rare: a caller-assigned covariance) keeps the way through memory.
-        lds_sync<true>();
-        const bool dense = sh_dense != 0;
-        if (dense) __syncthreads();
-        plan_block<1, STEP_NW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem),
-                               dense ? nullptr : sh_plan);
+        __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
+        plan_block<1, STEP_NW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
     }
 }
 
