@@ -302,6 +302,15 @@ typedef struct av_yolo av_yolo;
 size_t av_yolo_param_count(void);
 int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights,
                    av_yolo** out);
+/* The same with a choice of arithmetic.  AV_YOLO_FP16 (av_yolo_create): IEEE-half tensors, weights and MFMA operands, float32
+ * accumulation -- the fused production path.  AV_YOLO_FP32: the reference's own precision (ultralytics runs torch float32,
+ * detector.py:103-123): float32 tensors, weights and MFMA operands (v_mfma_f32_16x16x4_f32), one generic convolution kernel, no
+ * fusion, no deferred tail -- the checking mode for the half-precision path and a second bench figure.  Same entry points otherwise;
+ * av_yolo_tensor then returns float32 data. */
+#define AV_YOLO_FP16 0
+#define AV_YOLO_FP32 1
+int av_yolo_create_ex(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights, int precision,
+                      av_yolo** out);
 int av_yolo_destroy(av_yolo* h);
 int av_yolo_dims(const av_yolo* h, int* net_h, int* net_w, int* n_anchors);        /* host out */
 /*   bgr      u8 [batch][in_h][in_w][3] (device)

@@ -132,6 +132,7 @@ _SIGS = [
     ("av_maneuver_detect", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     ("av_yolo_param_count", C.c_size_t, []),
     ("av_yolo_create", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(vp)]),
+    ("av_yolo_create_ex", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(vp)]),
     ("av_yolo_destroy", C.c_int, [vp]),
     ("av_yolo_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("av_yolo_forward", C.c_int, [vp, vp, vp, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),

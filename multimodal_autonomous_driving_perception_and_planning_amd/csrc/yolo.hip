@@ -1921,7 +1921,154 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
 }
 
 // ---- host side: graph of layers --------------------------------------------------------------------------------
-struct Buf { half_t* p = nullptr; int C = 0, H = 0, W = 0; };
+
+// ---- reference-precision mode (av_yolo_create_ex(..., AV_YOLO_FP32)) ------------------------------------------------------------
+// The reference runs ultralytics on torch float32 (detector.py:103-123).  The production path above takes IEEE-half operands; this
+// mode keeps EVERY tensor and weight in float32 and multiplies on v_mfma_f32_16x16x4_f32 (float32 operands, float32 accumulation):
+// one generic implicit-GEMM kernel for all 63 convolutions, no fusion, one lane.  It is the checker for the half-precision path
+// (tests/test_gpu_yolo.py: maps and logits to 1e-5 of their maximum against the PyTorch-CPU oracle) and a second bench figure.
+//
+// conv_f32_kernel<MT, NT, CB>: a wave owns 16 MT output channels x 16 NT output pixels (flattened over batch, rows, columns); no LDS:
+// a lane's A operand is 4 consecutive input channels of one weight row, its B operand 4 consecutive channels of one input pixel
+// (both one 16-byte load from NHWC / [cout][tap][cin] memory), used for 4 MFMA steps.  Within a block of CB = 16 channels step s
+// therefore contracts channels {s, 4 + s, 8 + s, 12 + s} -- a permutation of the K order, the same on both operands.  The next
+// block's operands are requested before the current block's MFMAs.  CB = 4: the stem (3 image channels + a zero), one step per tap.
+struct ConvArgsF {
+    const float* in;  int in_cs, in_coff, cin, H, W;
+    const float* wgt; const float* bias; int ksz, stride;
+    float* out;       int out_cs, out_coff, cout, Ho, Wo;
+    const float* res; int res_cs, res_coff;
+    int act, npix;
+};
+
+template <int MT, int NT, int CB>
+__global__ void __launch_bounds__(256) conv_f32_kernel(ConvArgsF a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
+    const int p0 = ((int)blockIdx.x * 4 + wave) * (16 * NT), co0 = (int)blockIdx.y * (16 * MT);
+    if (p0 >= a.npix) return;
+    const int taps = a.ksz * a.ksz, pad = a.ksz / 2, K = taps * a.cin;
+    int pb[NT], py[NT], px[NT];
+    bool pv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = p0 + nt * 16 + j;
+        pv[nt] = p < a.npix;
+        const int q = pv[nt] ? p : 0;
+        pb[nt] = q / (a.Ho * a.Wo);
+        const int r = q - pb[nt] * a.Ho * a.Wo;
+        py[nt] = r / a.Wo, px[nt] = r - py[nt] * a.Wo;
+    }
+    const float* wrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wrow[mt] = a.wgt + (size_t)(co0 + mt * 16 + j) * K + (CB == 16 ? 4 * kk : kk);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nblk = a.cin / CB, steps = taps * nblk;
+    f32x4 A[2][MT], Bv[2][NT];
+    auto request = [&](int st, int buf) {
+        const int tap = st / nblk, c0 = (st - tap * nblk) * CB;
+        const int ky = tap / a.ksz, kx = tap - ky * a.ksz;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (CB == 16) A[buf][mt] = *reinterpret_cast<const f32x4*>(wrow[mt] + tap * a.cin + c0);
+            else A[buf][mt] = f32x4{wrow[mt][tap * a.cin + c0], 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int iy = py[nt] * a.stride + ky - pad, ix = px[nt] * a.stride + kx - pad;
+            const bool inb = pv[nt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const float* src = a.in + ((size_t)(pb[nt] * a.H + (inb ? iy : 0)) * a.W + (inb ? ix : 0)) * a.in_cs + a.in_coff + c0 + (CB == 16 ? 4 * kk : kk);
+            f32x4 v;
+            if (CB == 16) v = *reinterpret_cast<const f32x4*>(src);
+            else v = f32x4{*src, 0.f, 0.f, 0.f};
+            Bv[buf][nt] = inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    request(0, 0);
+    for (int st = 0; st < steps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < steps) request(st + 1, cur ^ 1);
+#pragma unroll
+        for (int s4 = 0; s4 < (CB == 16 ? 4 : 1); ++s4)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][mt][s4], Bv[cur][nt][s4], acc[mt][nt], 0, 0, 0);
+    }
+    // D[i = 4 (lane / 16) + r][j = lane % 16]: four consecutive output channels of pixel j per lane
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!pv[nt]) continue;
+        const size_t p = (size_t)(p0 + nt * 16 + j);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = co0 + mt * 16 + 4 * kk;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + co);
+            f32x4 v = acc[mt][nt] + bs;
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));          // SiLU = x * sigmoid(x)
+            }
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.res_cs + a.res_coff + co);
+            *reinterpret_cast<f32x4*>(a.out + p * a.out_cs + a.out_coff + co) = v;
+        }
+    }
+}
+
+// letterbox + bilinear resize + BGR -> RGB + / 255 -> NHWC4 float (channel 3 zero), [B][H][W][4]: preprocess_kernel's arithmetic
+__global__ void preprocess_f32_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
+                                      int top, int left, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int n = i / (H * W), r = i - n * H * W, y = r / W, x = r - y * W;
+    float c[3] = {114.f, 114.f, 114.f};
+    const int yy = y - top, xx = x - left;
+    if (yy >= 0 && yy < nh && xx >= 0 && xx < nw) {
+        const float sy = ((float)yy + 0.5f) * ((float)h / (float)nh) - 0.5f, sx = ((float)xx + 0.5f) * ((float)w / (float)nw) - 0.5f;
+        const float fy = floorf(sy), fx = floorf(sx);
+        const float wy = sy - fy, wx = sx - fx;
+        int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0), y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+        x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0), x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+        const uint8_t* im = bgr + (size_t)n * h * w * 3;
+        for (int q = 0; q < 3; ++q) {
+            const float p00 = im[((size_t)y0 * w + x0) * 3 + q], p01 = im[((size_t)y0 * w + x1) * 3 + q];
+            const float p10 = im[((size_t)y1 * w + x0) * 3 + q], p11 = im[((size_t)y1 * w + x1) * 3 + q];
+            const float ta = p00 * (1.f - wx) + p01 * wx, tb = p10 * (1.f - wx) + p11 * wx;
+            c[q] = floorf(ta * (1.f - wy) + tb * wy + 0.5f);
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = f32x4{c[2] / 255.f, c[1] / 255.f, c[0] / 255.f, 0.f};   // RGB
+}
+
+__global__ void maxpool5_f32_kernel(const float* in, int cs_in, int coff_in, float* out, int cs_out, int coff_out, int B, int H, int W, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W * C) return;
+    const int c = i % C, p = i / C, n = p / (H * W), r = p - n * H * W, y = r / W, x = r - y * W;
+    float m = -INFINITY;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            m = fmaxf(m, in[((size_t)(n * H + yy) * W + xx) * cs_in + coff_in + c]);
+        }
+    out[(size_t)p * cs_out + coff_out + c] = m;
+}
+
+__global__ void upsample2_f32_kernel(const float* in, int cs_in, int coff_in, float* out, int cs_out, int coff_out, int B, int H, int W, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // H, W: input size; output 2H x 2W, nearest
+    const int C4 = C / 4;
+    if (i >= B * 4 * H * W * C4) return;
+    const int c4 = i % C4, p = i / C4, n = p / (4 * H * W), r = p - n * 4 * H * W, y = r / (2 * W), x = r - y * 2 * W;
+    *reinterpret_cast<f32x4*>(out + (size_t)p * cs_out + coff_out + c4 * 4) =
+        *reinterpret_cast<const f32x4*>(in + ((size_t)(n * H + (y >> 1)) * W + (x >> 1)) * cs_in + coff_in + c4 * 4);
+}
+
+struct Buf { half_t* p = nullptr; int C = 0, H = 0, W = 0; };     // (reference-precision mode: the same pointer holds float elements)
 struct Slice { int buf, coff, c; };
 
 struct Yolo {
@@ -1929,7 +2076,8 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
-    struct Op { int kind; ConvArgs ca; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; int vcat = -1; };   // lane 1: internal side stream;
+    bool f32 = false;                    // reference-precision mode: float32 tensors and weights, conv_f32_kernel, no fusion
+    struct Op { int kind; ConvArgs ca; ConvArgsF cf; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; int vcat = -1; };   // lane 1: internal side stream;
     // vcat >= 0 (an upsample op): op index of the 1x1 convolution that can read this upsample's source directly (virtual Upsample + Concat);
     // fuse 1: this op and the next three are a C2f block c2f16_fused_kernel can run in one launch; 2 / 3: 32-channel blocks (c2f32_*); dec 1 / 2: the head's last box /
     // class convolution of level dec_level (its epilogue can do the decode)
@@ -1967,7 +2115,7 @@ bool dev_alloc(Yolo& y, void** p, size_t bytes) {
 int new_buf(Yolo& y, int H, int W, int C) {
     Buf b;
     b.C = C, b.H = H, b.W = W;
-    if (!dev_alloc(y, (void**)&b.p, (size_t)y.B * H * W * C * sizeof(half_t))) return -1;
+    if (!dev_alloc(y, (void**)&b.p, (size_t)y.B * H * W * C * (y.f32 ? sizeof(float) : sizeof(half_t)))) return -1;
     y.bufs.push_back(b);
     return (int)y.bufs.size() - 1;
 }
@@ -1982,6 +2130,48 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
     const float* w = y.wsrc + y.wpos;
     const float* bp = w + nw;
     y.wpos += nw + nb;
+    if (y.f32) {
+        // float32 weights [cout][tap][cin] with BatchNorm folded in float32 (gamma / sqrt(var + eps) applied to the weights, as
+        // ultralytics' fuse() does); an input of 4 channels whose parameters have 3 (the stem) gets a zero fourth channel
+        const int cin_w = (cin == 4 && k == 3 && s == 2 && y.ops.empty()) ? 3 : cin;
+        const size_t nwf = (size_t)cout * cin_w * taps;
+        y.wpos -= nw + nb;
+        if (y.wpos + nwf + nb > y.wtotal) return false;
+        const float* bpf = w + nwf;
+        y.wpos += nwf + nb;
+        std::vector<float> wf((size_t)cout * taps * cin, 0.f), bias(cout);
+        for (int co = 0; co < cout; ++co) {
+            float scale = 1.f, sh = bpf[co];
+            if (bn_act) {
+                const float g = bpf[co], be = bpf[cout + co], mu = bpf[2 * cout + co], var = bpf[3 * cout + co];
+                scale = g / std::sqrt(var + 1e-3f);
+                sh = be - mu * scale;
+            }
+            bias[co] = sh;
+            for (int ci = 0; ci < cin_w; ++ci)
+                for (int t = 0; t < taps; ++t) wf[((size_t)co * taps + t) * cin + ci] = w[((size_t)co * cin_w + ci) * taps + t] * scale;
+        }
+        float *dw, *db;
+        if (!dev_alloc(y, (void**)&dw, wf.size() * 4) || !dev_alloc(y, (void**)&db, bias.size() * 4)) return false;
+        (void)hipMemcpy(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice);
+        const Buf& bi = y.bufs[in.buf];
+        Yolo::Op op{};
+        op.kind = 10;
+        ConvArgsF& a = op.cf;
+        a.in = reinterpret_cast<const float*>(bi.p), a.in_cs = bi.C, a.in_coff = in.coff, a.cin = cin, a.H = bi.H, a.W = bi.W;
+        a.wgt = dw, a.bias = db, a.ksz = k, a.stride = s;
+        a.Ho = (bi.H + 2 * (k / 2) - k) / s + 1, a.Wo = (bi.W + 2 * (k / 2) - k) / s + 1;
+        if (out32) a.out = out32, a.out_cs = out32_cs, a.out_coff = 0;
+        else a.out = reinterpret_cast<float*>(y.bufs[out.buf].p), a.out_cs = y.bufs[out.buf].C, a.out_coff = out.coff;
+        a.cout = cout;
+        a.res = nullptr, a.res_cs = 0, a.res_coff = 0;
+        if (res) a.res = reinterpret_cast<const float*>(y.bufs[res->buf].p), a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
+        a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
+        op.mt = (cout % 64 == 0) ? 4 : ((cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1));
+        y.ops.push_back(op);
+        return true;
+    }
     std::vector<half_t> wb((size_t)cout * kpad, (half_t)0);
     std::vector<float> bias(cout);
     for (int co = 0; co < cout; ++co) {
@@ -2307,7 +2497,12 @@ int av_yolo_destroy(av_yolo* h) {
 }
 
 int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights, av_yolo** out) {
+    return av_yolo_create_ex(ctx, batch, in_h, in_w, weights, n_weights, AV_YOLO_FP16, out);
+}
+
+int av_yolo_create_ex(av_ctx* ctx, int batch, int in_h, int in_w, const float* weights, size_t n_weights, int precision, av_yolo** out) {
     AV_REQUIRE(ctx && weights && out, AV_EINVAL, "av_yolo_create: null argument");
+    AV_REQUIRE(precision == AV_YOLO_FP16 || precision == AV_YOLO_FP32, AV_EINVAL, "av_yolo_create_ex: unknown precision %d", precision);
     AV_REQUIRE(batch > 0 && in_h >= 32 && in_w >= 32, AV_EINVAL, "av_yolo_create: bad shape");
     AV_REQUIRE(n_weights == av_yolo_param_count(), AV_EINVAL, "av_yolo_create: expected %zu parameters, got %zu",
                av_yolo_param_count(), n_weights);
@@ -2316,11 +2511,12 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     AV_REQUIRE(h, AV_ENOMEM, "av_yolo_create: out of host memory");
     Yolo& y = h->y;
     y.ctx = ctx, y.B = batch, y.inH = in_h, y.inW = in_w, y.wsrc = weights, y.wtotal = n_weights;
+    y.f32 = precision == AV_YOLO_FP32;
     letterbox(in_h, in_w, y.gain, y.nh, y.nw, y.top, y.left, y.H, y.W);
     bool ok = true;
     const int H = y.H, W = y.W;
     auto nb = [&](int hh, int ww, int c) { const int b = new_buf(y, hh, ww, c); ok = ok && b >= 0; return b; };
-    const int x0 = nb(H + 2, W + 2, 4), b0 = nb(H / 2, W / 2, 16), b1 = nb(H / 4, W / 4, 32), b2 = nb(H / 4, W / 4, 32);
+    const int x0 = y.f32 ? nb(H, W, 4) : nb(H + 2, W + 2, 4), b0 = nb(H / 2, W / 2, 16), b1 = nb(H / 4, W / 4, 32), b2 = nb(H / 4, W / 4, 32);
     const int cat14 = nb(H / 8, W / 8, 192), cat11 = nb(H / 16, W / 16, 384), cat20 = nb(H / 32, W / 32, 384);
     const int cat17 = nb(H / 16, W / 16, 192);
     const int b3 = nb(H / 8, W / 8, 64), b5 = nb(H / 16, W / 16, 128), b7 = nb(H / 32, W / 32, 256), b8 = nb(H / 32, W / 32, 256);
@@ -2329,7 +2525,8 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     (void)d16;
     if (!ok) { av_yolo_destroy(h); av_set_error("av_yolo_create: device allocation failed"); return AV_ENOMEM; }
 #define CV(...) ok = ok && add_conv(y, __VA_ARGS__)
-    ok = ok && add_stem(y, Slice{x0, 0, 4}, Slice{b0, 0, 16});                                    // 0
+    if (y.f32) CV(Slice{x0, 0, 4}, Slice{b0, 0, 16}, 3, 2, true, nullptr, 0, nullptr);           // 0 (4-channel input, fourth channel zero)
+    else ok = ok && add_stem(y, Slice{x0, 0, 4}, Slice{b0, 0, 16});                               // 0
     CV(Slice{b0, 0, 16}, Slice{b1, 0, 32}, 3, 2, true, nullptr, 0, nullptr);                      // 1
     ok = ok && add_c2f(y, Slice{b1, 0, 32}, Slice{b2, 0, 32}, 1, true);                            // 2
     CV(Slice{b2, 0, 32}, Slice{b3, 0, 64}, 3, 2, true, nullptr, 0, nullptr);                      // 3
@@ -2339,7 +2536,7 @@ int av_yolo_create(av_ctx* ctx, int batch, int in_h, int in_w, const float* weig
     CV(Slice{cat11, 256, 128}, Slice{b7, 0, 256}, 3, 2, true, nullptr, 0, nullptr);               // 7
     ok = ok && add_c2f(y, Slice{b7, 0, 256}, Slice{b8, 0, 256}, 1, true);                          // 8
     CV(Slice{b8, 0, 256}, Slice{spp, 0, 128}, 1, 1, true, nullptr, 0, nullptr);                   // 9 SPPF cv1
-    if ((H / 32) * (W / 32) <= 1024) {       // all three pools from one LDS copy of the map
+    if ((H / 32) * (W / 32) <= 1024 && !y.f32) {       // all three pools from one LDS copy of the map
         add_simple(y, 3, Slice{spp, 0, 128}, Slice{spp, 128, 384}, H / 32, W / 32, 128);
     } else {
         for (int i = 0; i < 3; ++i) add_simple(y, 1, Slice{spp, 128 * i, 128}, Slice{spp, 128 * (i + 1), 128}, H / 32, W / 32, 128);
@@ -2491,6 +2688,51 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         }
     }
     size_t first_op = 0;
+    if (y.f32) {
+        // reference-precision chain: one lane, one launch per layer, float32 logits, stand-alone decode
+        AV_REQUIRE(!y.defer_tail, AV_ESTATE, "av_yolo_forward: the float32 mode has no deferred tail");
+        const int n = B * y.H * y.W;
+        hipLaunchKernelGGL(preprocess_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bgr, B, y.inH, y.inW, y.H, y.W, y.nh, y.nw, y.top,
+                           y.left, reinterpret_cast<float*>(y.bufs[0].p));
+        AV_LAUNCH_CHECK();
+        for (const Yolo::Op& op : y.ops) {
+            if (op.kind == 10) {
+                const ConvArgsF& a = op.cf;
+                constexpr int NT = 4;
+                const dim3 grid((a.npix + 64 * NT - 1) / (64 * NT), a.cout / (16 * op.mt));
+#define AV_CF(MTV)                                                                                      \
+    do {                                                                                                \
+        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NT, 16>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_f32_kernel<MTV, NT, 4>), grid, dim3(256), 0, st, a);              \
+    } while (0)
+                AV_REQUIRE(a.cin % 16 == 0 || a.cin == 4, AV_EINVAL, "av_yolo_forward: float32 convolution with %d input channels", a.cin);
+                AV_REQUIRE(a.cout == 16 * op.mt * (int)grid.y, AV_EINVAL, "av_yolo_forward: float32 convolution with %d output channels", a.cout);
+                if (op.mt == 4) AV_CF(4);
+                else if (op.mt == 5) AV_CF(5);
+                else if (op.mt == 2) AV_CF(2);
+                else AV_CF(1);
+#undef AV_CF
+            } else {
+                const Buf &bi = y.bufs[op.in.buf], &bo = y.bufs[op.out.buf];
+                const float* src = reinterpret_cast<const float*>(bi.p);
+                float* dst = reinterpret_cast<float*>(bo.p);
+                if (op.kind == 1) {
+                    const int m = B * op.H * op.W * op.C;
+                    hipLaunchKernelGGL(maxpool5_f32_kernel, dim3((m + 255) / 256), dim3(256), 0, st, src, bi.C, op.in.coff, dst, bo.C, op.out.coff,
+                                       B, op.H, op.W, op.C);
+                } else if (op.kind == 2) {
+                    const int m = B * 4 * op.H * op.W * (op.C / 4);
+                    hipLaunchKernelGGL(upsample2_f32_kernel, dim3((m + 255) / 256), dim3(256), 0, st, src, bi.C, op.in.coff, dst, bo.C, op.out.coff,
+                                       B, op.H, op.W, op.C);
+                } else {
+                    av_set_error("av_yolo_forward: op kind %d has no float32 form", op.kind);
+                    return AV_EINVAL;
+                }
+            }
+            AV_LAUNCH_CHECK();
+        }
+        first_op = y.ops.size();
+    } else
     {
         const int n = B * y.H * y.W;
         const bool twice = y.inH == 2 * y.nh && y.inW == 2 * y.nw && y.inW % 4 == 0 && (reinterpret_cast<uintptr_t>(bgr) & 3) == 0 &&
@@ -2636,7 +2878,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         const int rc = launch_op(y, op, (y.side && op.lane) ? y.side : st_main, B, force_direct);
         if (rc != AV_OK) return rc;
     }
-    if (y.side && y.head_begin >= 0) {                     // the decode reads both branches
+    if (y.side && y.head_begin >= 0 && !y.f32) {           // the decode reads both branches
         AV_HIP(hipEventRecord(y.ev_join, y.side));
         AV_HIP(hipStreamWaitEvent(st_main, y.ev_join, 0));
     }
@@ -2655,6 +2897,10 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
     }
     // The candidates (cbox / cconf / ccls) were written by the head's last convolutions.  With keep_logits the stand-alone
     // decode runs as well, from the float32 logits into buffers of its own: the test hook that shows the two are equal.
+    if (y.f32) {                                           // the float32 chain keeps its logits: the stand-alone decode IS its decode
+        hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.cbox, y.cconf, y.ccls);
+        AV_LAUNCH_CHECK();
+    } else
     if (y.keep_logits) {
         hipLaunchKernelGGL(decode_kernel, dim3((B * y.A + 127) / 128), dim3(128), 0, st, lv[0], lv[1], lv[2], y.A, B, y.dbg_cbox,
                            y.dbg_cconf, y.dbg_ccls);

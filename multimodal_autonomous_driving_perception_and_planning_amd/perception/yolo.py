@@ -190,9 +190,14 @@ class _OwnStream:
 
 
 class YoloV8n:
-    def __init__(self, model_path="random", device=0, batch=1, keep_logits=False):
+    def __init__(self, model_path="random", device=0, batch=1, keep_logits=False, precision="fp16"):
         """keep_logits: test hook -- the head also writes its float32 logits (tensor ids 100-105) and the stand-alone decode
-        runs on them (ids 120-122); normally the decode happens in the head's last convolutions and no logits exist."""
+        runs on them (ids 120-122); normally the decode happens in the head's last convolutions and no logits exist.
+        precision: "fp16" -- IEEE-half tensors / weights / MFMA operands with float32 accumulation, the fused production path;
+        "fp32" -- the reference's own arithmetic (ultralytics on torch float32, detector.py:103-123): float32 everywhere on
+        v_mfma_f32_16x16x4_f32, one generic kernel per layer, logits always kept (ids 100-105)."""
+        if precision not in ("fp16", "fp32"):
+            raise ValueError("precision must be 'fp16' or 'fp32', got %r" % (precision,))
         self._dev = Dev(device)
         self.keep_logits = keep_logits
         self.params = load_params(model_path)
@@ -201,7 +206,7 @@ class YoloV8n:
             raise ValueError("parameter vector has %d floats, the YOLOv8n graph needs %d" % (self.params.size, n))
         self.names = dict(enumerate(COCO_NAMES))
         self.batch = batch
-        self.precision = "fp16"          # activations / weights / MFMA operands are IEEE half, accumulation float32
+        self.precision = precision
         self._h = None
         self._shape = None
         self._io_in = self._io_out = None      # per-frame call: pinned upload buffer, host-mapped result buffer
@@ -220,8 +225,8 @@ class YoloV8n:
         d = self._dev
         self.close()
         hd = C.c_void_p()
-        nat.check(d.lib.av_yolo_create(d.ctx.handle, self.batch, h, w, self.params.ctypes.data_as(C.c_void_p),
-                                       self.params.size, C.byref(hd)))
+        nat.check(d.lib.av_yolo_create_ex(d.ctx.handle, self.batch, h, w, self.params.ctypes.data_as(C.c_void_p),
+                                          self.params.size, 1 if self.precision == "fp32" else 0, C.byref(hd)))
         self._h = hd
         self._shape = (h, w)
         if self.keep_logits:
@@ -276,7 +281,7 @@ class YoloV8n:
                                             o.ptr("conf"), o.ptr("cls")))
         key = (float(conf), float(iou))
         gid = self._graphs.get(key)
-        if gid is None and self.use_graph and key in self._warm and not self.keep_logits:
+        if gid is None and self.use_graph and key in self._warm and not self.keep_logits and self.precision == "fp16":
             # second call with these thresholds: every one-time host action of the forward (symbol uploads, attributes) is behind us
             g = C.c_int(-1)
             nat.check(d.lib.av_graph_begin(d.ctx.handle, d.stream))
@@ -300,10 +305,10 @@ class YoloV8n:
         p, H, W, Cc, cs, co = C.c_void_p(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         nat.check(self._dev.lib.av_yolo_tensor(self._h, tid, C.byref(p), C.byref(H), C.byref(W), C.byref(Cc), C.byref(cs),
                                                C.byref(co)))
-        if 100 <= tid < 106 and not self.keep_logits:
-            raise RuntimeError("head logits exist only in a YoloV8n(keep_logits=True)")
+        if 100 <= tid < 106 and not (self.keep_logits or self.precision == "fp32"):
+            raise RuntimeError("head logits exist only in a YoloV8n(keep_logits=True) or in float32 mode")
         n = self.batch * H.value * W.value * cs.value
-        t = torch.empty(n, dtype=torch.float32 if tid >= 100 else torch.int16, device=self._dev.device)
+        t = torch.empty(n, dtype=torch.float32 if (tid >= 100 or self.precision == "fp32") else torch.int16, device=self._dev.device)
         nbytes = t.numel() * t.element_size()
         self._dev.sync()
         rc = _memcpy_d2d(t.data_ptr(), p.value, nbytes)      # the tensor lives in library-owned memory
@@ -314,7 +319,7 @@ class YoloV8n:
             arr = arr[image]
         if tid in (112, 122):
             return np.ascontiguousarray(arr).view(np.int32)
-        if tid >= 100:
+        if tid >= 100 or self.precision == "fp32":
             return arr.astype(np.float32)
         if self.precision == "bf16":                       # (a library built with bf16 activations: comparison runs only)
             return (arr.astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
