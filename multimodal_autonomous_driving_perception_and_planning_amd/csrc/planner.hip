@@ -790,19 +790,19 @@ int av_planner_plan(av_ctx* ctx, av_stream_t stream, int n_states, const double*
     fill_params(ctx, p);
     hipStream_t st = as_stream(stream);
     if (n <= 64 && n_states >= 1024) {
-        // states per wave: 2 (103-KB output regions); AVHOT_PLAN_FPW=1: one state per wave (51-KB regions, twice the waves)
-        const char* fe = getenv("AVHOT_PLAN_FPW");
-        const int fpw = fe && atoi(fe) == 1 ? 1 : 2;
-        const size_t per_wave = (size_t)fpw * 3 * n * 2 + RING_DOUBLES + even_up(fpw * C) + fpw * 3 * 4 + fpw * 8;
+        // two states per wave (103-KB output regions); one per wave -- 51-KB regions, twice the waves -- measured the same
+        // (59.4-60.7 % of HBM peak at 16 384 states either way, alternating runs on one box)
+        constexpr int FPW = 2;
+        const size_t per_wave = (size_t)FPW * 3 * n * 2 + RING_DOUBLES + even_up(FPW * C) + FPW * 3 * 4 + FPW * 8;
         const size_t lds_w = per_wave * 4 * sizeof(double);
         if (lds_w <= 64 * 1024) {
-            const int grid_w = (n_states + 4 * fpw - 1) / (4 * fpw);
-            const bool extra = n_ref > 0 || n_obs > 0;
-#define AV_PW(F, E) hipLaunchKernelGGL((planner_wave_kernel<F, E>), dim3(grid_w), dim3(256), lds_w, st, p, n_states, state, \
-                                       ref_path, n_ref, obstacles, n_obs, waypoints, cost, order)
-            if (fpw == 1) { if (extra) AV_PW(1, true); else AV_PW(1, false); }
-            else { if (extra) AV_PW(2, true); else AV_PW(2, false); }
-#undef AV_PW
+            const int grid_w = (n_states + 4 * FPW - 1) / (4 * FPW);
+            if (n_ref > 0 || n_obs > 0)
+                hipLaunchKernelGGL((planner_wave_kernel<FPW, true>), dim3(grid_w), dim3(256), lds_w, st, p, n_states, state,
+                                   ref_path, n_ref, obstacles, n_obs, waypoints, cost, order);
+            else
+                hipLaunchKernelGGL((planner_wave_kernel<FPW, false>), dim3(grid_w), dim3(256), lds_w, st, p, n_states, state,
+                                   ref_path, n_ref, obstacles, n_obs, waypoints, cost, order);
             AV_LAUNCH_CHECK();
             return AV_OK;
         }
