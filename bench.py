@@ -38,7 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PF
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / f16 MFMA ~2.5 PF
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: float32-operand MFMA (v_mfma_f32_16x16x4_f32) = the float32 vector rate
 N_CUS = 256
 CPU_SHARE = 16                 # host cores that go with one GPU of an 8-GPU node (process / thread pools are sized to it)
 PKG = "multimodal_autonomous_driving_perception_and_planning_amd"
@@ -68,6 +69,7 @@ def parse():
     ap.add_argument("--native-allgather", action="store_true",
                     help="N>1: gather with the library's own av_allgather_tracks (RCCL communicator made from a broadcast "
                          "ncclUniqueId) instead of torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"], help="config3: detector arithmetic")
     ap.add_argument("--min-seconds", type=float, default=0.2, help="least device time behind every reported figure")
     ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
                     help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
@@ -431,15 +433,17 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
 # ---------------------------------------------------------------------------------------------------------------
 # config 3: YOLO-mode detector + lane detector on device-generated frames
 # ---------------------------------------------------------------------------------------------------------------
-def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
+def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6, precision="fp16"):
     import torch
     import torch.distributed as dist
     from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
     from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import PerceptionLoop
-    loop = PerceptionLoop(n_streams=S, device=local)
+    loop = PerceptionLoop(n_streams=S, device=local, precision=precision)
     L = nat.lib()
     s, side = loop._s, loop.ctx.side_stream
-    if not a.no_defer:
+    fp32 = precision == "fp32"
+    mfma_peak = MFMA_F32_PEAK_TFLOPS if fp32 else MFMA_PEAK_TFLOPS
+    if not a.no_defer and not fp32:
         loop.defer_detector_tail(True)       # decode + sort + NMS of step k beside the convolutions of step k+1
 
     def one_step():
@@ -481,7 +485,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     el = time.perf_counter() - t0
     el, per_rank_ms = max_over_ranks(el, world)
 
-    loop.defer_detector_tail(False)          # the per-stage times below are of whole stages
+    if not fp32:
+        loop.defer_detector_tail(False)      # the per-stage times below are of whole stages
     sync = loop.synchronize
     t_gen = time_stage(L, nat, s, loop.enqueue_generate, stage_reps, sync)
     t_yolo = time_stage(L, nat, s, loop.enqueue_detect, stage_reps, sync)
@@ -492,12 +497,14 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
     tf = fl / (t_yolo * 1e-3) / 1e12
     pix_bytes = loop.lane_pixel_bytes_per_px * px
     ks = [
-        {"kernel": "yolo forward: front_fused_kernel (letterbox + stem + layer 1) + c2f16_fused_kernel (layer 2) + c2f32_head/tail "
-                   "kernels (layers 4, 15) + 47 conv launches (conv3x3_ws_kernel / conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel; "
-                   "decode in the head's last convolutions) + sppf + upsample + radix sort + NMS", "stage": "detect", "branch": "main",
+        {"kernel": ("yolo forward, float32 operands: preprocess + 63 conv_f32_kernel launches (v_mfma_f32_16x16x4_f32, one generic "
+                    "implicit-GEMM kernel, no fusion) + 3 max-pools + 2 upsamples + decode + radix sort + NMS") if fp32 else
+                   ("yolo forward: front_fused_kernel (letterbox + stem + layer 1) + c2f16_fused_kernel (layer 2) + c2f32_head/tail "
+                    "kernels (layers 4, 15) + 47 conv launches (conv3x3_ws_kernel / conv1x1_ws_kernel / conv_lds_kernel / conv_mfma_kernel; "
+                    "decode in the head's last convolutions) + sppf + upsample + radix sort + NMS"), "stage": "detect", "branch": "main",
          "avg_ms": t_yolo, "bound": "mfma",
-         "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-         "frac": round(tf / MFMA_PEAK_TFLOPS, 4)},
+         "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s",
+         "frac": round(tf / mfma_peak, 4)},
         {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",
          "avg_ms": t_pix, "bound": "hbm", "bytes_per_launch": pix_bytes,
          "achieved": round(pix_bytes / (t_pix * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -520,13 +527,14 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6):
             "avg_launch_ms": round(dom["avg_ms"], 5)}
     if "flops_per_launch" in dom:
         roof["flops_per_launch"] = dom["flops_per_launch"]
-        roof["mfma_busy_pmc_percent"] = pmc_value("yolo_mfma_pmc.json", "overall_mfma_busy_percent")
+        if not fp32:
+            roof["mfma_busy_pmc_percent"] = pmc_value("yolo_mfma_pmc.json", "overall_mfma_busy_percent")
     out = {"metric": METRIC, "value": round(S * nsteps * world / el, 1), "unit": "frames/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "inner_reps": reps, "timed_s": round(el, 4),
            "ms_per_step": round(el / nsteps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": loop.yolo.precision, "data": "synthetic (generated on device)",
            "config": {"workload": "config3: %d camera streams/GPU, one 1280x720 frame of each per step, YOLO-mode detector "
-                                  "(random-init YOLOv8n topology, letterbox 384x640) + Canny/Hough lane detector" % S,
+                                  "(random-init YOLOv8n topology, letterbox 384x640%s) + Canny/Hough lane detector" % (S, ", float32 operands: the reference's own precision" if fp32 else ", IEEE-half operands"),
                       "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
            "roofline": roof, "kernels": finish_kernel_list(ks),
            "lane_chain": {"avg_ms": round(lane_ms, 5), "bytes_per_launch": lane_total,
@@ -697,7 +705,7 @@ def main():
         return run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup)
 
     if a.workload == "config3":
-        head = with_cpu(run_config3(a, world, rank, local, a.streams or 64, a.steps, a.warmup), cpu_pix)
+        head = with_cpu(run_config3(a, world, rank, local, a.streams or 64, a.steps, a.warmup, precision=a.precision), cpu_pix)
     elif a.workload == "config2":
         g = bool(a.graph) if a.graph is not None else False
         head = with_cpu(hot("config2", a.streams or 1, a.window or 131072, g, a.steps, a.warmup), cpu_hot)
@@ -714,6 +722,8 @@ def main():
         else:
             also["config4_w1"] = with_cpu(hot("config4 (window 1)", a.streams or 64, 1, False, 20, 5), cpu_hot)
         also["config3"] = with_cpu(run_config3(a, world, rank, local, 64, 20, 5), cpu_pix)
+        # the same configuration in the reference's own arithmetic (ultralytics runs float32): what the half-precision figure above is to be read against
+        also["config3_fp32"] = with_cpu(run_config3(a, world, rank, local, 64, 5, 2, stage_reps=3, precision="fp32"), cpu_pix)
         also["config2"] = with_cpu(hot("config2", 1, 32768, False, 4, 1), cpu_hot)
         also["config2_w1"] = with_cpu(hot("config2 (window 1)", 1, 1, False, 20, 5), cpu_hot)
         also["config4_256streams"] = with_cpu(hot("config4 scaled to 256 streams (not a BASELINE config: shows the "

@@ -289,14 +289,14 @@ class PerceptionLoop:
     """BASELINE config 3: S camera streams, frames generated on the device, YOLO-mode detector (MFMA conv
     path) + lane detector per frame.  Everything stays in HBM; one enqueue per stage per step."""
 
-    def __init__(self, n_streams=16, h=720, w=1280, device=0, model="random:0", max_segments=512, ctx=None):
+    def __init__(self, n_streams=16, h=720, w=1280, device=0, model="random:0", max_segments=512, ctx=None, precision="fp16"):
         if not torch.cuda.is_available():
             raise RuntimeError("PerceptionLoop needs a HIP device; this package has no CPU path")
         from .perception.yolo import MAX_DET, YoloV8n, conv_specs
         self.S, self.h, self.w, self.ms = n_streams, h, w, max_segments
         self.dev = torch.device("cuda", device)
         self.L = nat.lib()
-        self.yolo = YoloV8n(model, device=device, batch=n_streams)
+        self.yolo = YoloV8n(model, device=device, batch=n_streams, precision=precision)
         self.ctx = self.yolo._dev.ctx
         self.yolo._prepare(h, w)
         # the detector chain is the critical path when the lane chain runs beside it: higher queue priority
@@ -370,6 +370,8 @@ class PerceptionLoop:
     def defer_detector_tail(self, enable=True):
         """Throughput mode of the detector: decode + sort + NMS of step k beside the convolutions of step k+1
         (av_yolo_defer_tail); det_* are complete after flush_lanes() / join_detector_tail()."""
+        if enable and self.yolo.precision == "fp32":
+            raise RuntimeError("the float32 detector mode has no deferred tail")
         nat.check(self.L.av_yolo_defer_tail(self.yolo._h, 1 if enable else 0))
 
     def join_detector_tail(self):
