@@ -37,10 +37,14 @@ struct StepArgs {
 
 constexpr int STEP_NW = 8;
 
-__global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
+// PW: waves of a planner workgroup (the tracker role always runs on STEP_NW = 8; with PW = 16 its workgroups' other eight waves leave
+// at once).  The 3 C = 21 trajectories of a start state are dealt to the waves whole: eight waves take three rounds, sixteen two.
+template <int PW>
+__global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.S) {
+        if (PW > STEP_NW && tid >= STEP_NW * 64) return;
         const int s = blockIdx.x;
         if (tid == 0)
             simdet_frame<true>(s, s, 0, a.h, a.w, a.dcap, a.frame_count, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf, a.det_status);
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(STEP_NW * 64) hot_step_kernel(StepArgs a) {
             if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);   // (LDS form: kf_dense.inc)
         }
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
-        plan_block<1, STEP_NW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
+        plan_block<1, PW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
     }
 }
 
@@ -100,16 +104,19 @@ extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
                                (size_t)fc * dcap * 16 + 16;
     const size_t rep_bytes = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
     const size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
-    const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, STEP_NW) * 8;
+    const char* pwe = getenv("AVHOT_STEP_PW");
+    const int pw = pwe && atoi(pwe) == 8 ? 8 : 16;
+    const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, pw) * 8;
     const size_t lds = lds_t > lds_p ? lds_t : lds_p;
     // static __shared__ of the kernel (the Kalman bodies' arrays) counts against the same 64 KB
     static const size_t lds_static = [] {
         hipFuncAttributes fa{};
-        return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(hot_step_kernel)) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)16384;
+        return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(hot_step_kernel<16>)) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)16384;
     }();
     AV_REQUIRE(lds + lds_static <= 64 * 1024, AV_EINVAL, "av_hot_step: configuration needs %zu B of dynamic + %zu B of static LDS (limit 65536)",
                lds, lds_static);
-    hipLaunchKernelGGL(hot_step_kernel, dim3(2 * n_streams), dim3(STEP_NW * 64), lds, as_stream(stream), a);
+    if (pw == 16) hipLaunchKernelGGL(hot_step_kernel<16>, dim3(2 * n_streams), dim3(16 * 64), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(hot_step_kernel<8>, dim3(2 * n_streams), dim3(8 * 64), lds, as_stream(stream), a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) conv_gemm128_kernel(ConvArgs a) {
     for (int mt = 0; mt < 4; ++mt) bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch_base + wm * 64 + mt * 16 + 4 * h);
     gload(0);
     lstore(0);
-    gload(1);
+    if (NSTEP > 1) gload(1);                       // (cin = 64 with one tap is a single step: nothing behind it to request)
 #pragma unroll 1
     for (int tap = 0; tap < NSTEP; ++tap) {        // (`tap` counts steps: half taps)
         __syncthreads();                           // the step's slab is in LDS; the other buffer's readers (step - 1) are done
