@@ -2159,25 +2159,39 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
 
 // ---- L4b': PPHT with theta sharded over HG workgroups per frame, accumulator in LDS ------------------------------
 // houghp_fast is bound by its CU's L1/TA pipeline: every theta lane votes into its own 16-KB row of a global
-// accumulator, one cache line per lane per vote.  Here a frame is handled by HG workgroups (a main wave + a helper wave each,
-// see the kernel); workgroup g owns theta = HG*lane + g and keeps ONLY those rows, in LDS, over the rho range the points' bounding box can
-// reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed two to a word (PPHT's erase also
-// decrements pixels that have not voted yet, so counts go negative; |count| <= number of points <= 4096).  Every
+// accumulator, one cache line per lane per vote.  Here a frame is handled by HG = 16 workgroups (a main wave + a helper wave each,
+// see the kernel); workgroup g owns theta = HG * tl + g, tl = 0 .. 11, and keeps ONLY those twelve rows, in LDS, over the rho range
+// the points' bounding box can reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed two to a word (PPHT's
+// erase also decrements pixels that have not voted yet, so counts go negative; |count| <= number of points <= 4096).  Every
 // workgroup replays the same point list, RNG, FIFO, bitmap and line walks -- all deterministic -- so they stay
 // in step by construction and exchange just two words per batch through global memory: the mask of batch points
 // whose vote reached the threshold, and, when a line fires, their best (count, theta) key.  A word carries its
 // batch sequence number and is stored/loaded with agent scope (the XCDs' L2s are not coherent); slots are double-
 // buffered by sequence parity; every spin is bounded and a timeout hands the frame to houghp_fast.
-constexpr int HG = 4;
-constexpr int HS_NZ = 4096, HS_BMW = 11776, HS_ACCW = 24576;      // LDS capacities: points, bitmap words, accumulator words
+//
+// Round 4: sixteen shards of twelve rows instead of four of forty-five, for two reasons.
+//  * LDS: 79 KB per workgroup (accumulator 24 KB, point list 16 KB, live-pixel bitmap over the points' column range 36 KB) instead of
+//    158 KB -- two workgroups per CU, or one beside a convolution workgroup of the detector (config 3 runs the lane chain beside it;
+//    the 158-KB claim kept every LDS-tiled convolution off the CUs it ran on).  A frame's shards need not all be resident at once
+//    for progress: workgroups are dispatched in blockIdx order, so the frames in front complete and make room; a shard whose
+//    partners are still waiting for a slot just spins (bounded).
+//  * votes: a lane is (theta row tl, point slot sub) -- 12 x 5 = 60 lanes -- and ONE returning LDS atomic instruction casts the votes
+//    of five consecutive batch points: a batch of 32 is 7 instructions instead of 32.  A vote's returned count must include exactly
+//    the batch's EARLIER points on the same cell; the points of one instruction that hit the same cell sit in lanes tl, tl + 12,
+//    tl + 24, ... in batch order, and the LDS serves the lanes of one atomic instruction that address the same word in increasing
+//    lane order, each with the running value (tools/wldsorder.hip: 0 violations in 4 x 65 536 lanes over all-same, paired,
+//    quadruple and random address patterns, with and without a second wave hammering the same banks).
+constexpr int HG = 16, HTL = 12, HNS = 5, HNV = (HB + HNS - 1) / HNS;    // shards, theta rows per shard, point slots per instruction, vote instructions per batch
+constexpr int HS_NZ = 4096, HS_BMW = 9216, HS_ACCW = 6144;        // LDS capacities: points, bitmap words (288 rows x 32 words), accumulator words
 constexpr unsigned HS_BIAS = 0x4000u;
 constexpr int HS_SPIN = 1 << 20;              // default bound of every exchange spin (x s_sleep 2), ~0.1 s; AVHOT_HOUGH_SPIN overrides it
+static_assert(HG * HTL >= NUMANGLE && HTL * HNS <= 64 && HG <= 64, "shard geometry");
 
 __global__ void hough_prep_kernel(int n_streams, int numrho, int* __restrict__ accum_all, int* __restrict__ fallback) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_streams * 32) return;
-    const int s = i >> 5, k = i & 31;
-    accum_all[(size_t)s * NUMANGLE * numrho + k] = 0;              // 16 exchange words (8 bytes each)
+    if (i >= n_streams * 8 * HG) return;
+    const int s = i / (8 * HG), k = i - s * (8 * HG);
+    accum_all[(size_t)s * NUMANGLE * numrho + k] = 0;              // 2 rounds x 2 parities x HG exchange words (8 bytes each)
     if (k == 0) fallback[s] = 0;
 }
 
@@ -2208,14 +2222,11 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
     __shared__ int fifo[FIFO];
     __shared__ int bpt[HB];
     __shared__ float bfx[HB], bfy[HB];
-    __shared__ int row_sz[64];
+    __shared__ int row_sz[HG * HTL];
     __shared__ int sh_nb, sh_head, sh_tail, sh_count;
-    // Second wave = helper.  A lone wave issues one instruction per 5-8 cycles however independent they are (tools/wvalu.hip), and
-    // 47 % of this kernel was the vote phase + the FIFO top-up behind it, 17 % the erase of a fired line.  The helper wave (on another
-    // SIMD) runs every top-up -- beside the votes of the same batch -- and the second direction of every erase; it follows the
-    // main wave through a command word in LDS and a pair of workgroup barriers per command.  (A third wave voting half of a batch's
-    // points beside the main wave was built too, 247 us -- and dropped: the count a vote returns must include exactly the batch's
-    // EARLIER points, which two waves adding concurrently cannot guarantee; 1 run in 5 lost or gained a segment.)
+    // Second wave = helper.  A lone wave issues one instruction per 5-8 cycles however independent they are (tools/wvalu.hip).  The
+    // helper wave (on another SIMD) runs every FIFO top-up -- beside the votes and the exchange of the same batch -- and the second
+    // direction of every erase; it follows the main wave through a command word in LDS and a pair of workgroup barriers per command.
     __shared__ int sh_cmd, sh_er[12], sh_off[64], sh_big;
     enum { CMD_EXIT = 0, CMD_TOPUP = 1, CMD_ERASE = 2 };
     const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
@@ -2223,7 +2234,6 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(accum_all + (size_t)s * NUMANGLE * numrho);
     const int total = npts[s];
-    const int wpr = (w + 31) >> 5;
     auto give_up = [&]() {
         if (lane == 0) fallback[s] = 1;
     };
@@ -2252,17 +2262,26 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
 #pragma unroll
     for (int k = 0; k < NZ_PER; ++k) mine[k] = k * 64 + lane < total ? nzg[k * 64 + lane] : 0u;
     const int ymin = total > 0 ? (int)((unsigned)__builtin_amdgcn_readfirstlane((int)mine[0]) >> 16) : 0;
-    int ymax = 0;                                                                         // the list is sorted by (y, x)
+    int ymax = 0, xmn = w, xmx = 0;                                                       // the list is sorted by (y, x)
 #pragma unroll
-    for (int k = 0; k < NZ_PER; ++k) ymax = k * 64 + lane < total && (int)(mine[k] >> 16) > ymax ? (int)(mine[k] >> 16) : ymax;
+    for (int k = 0; k < NZ_PER; ++k) {
+        const bool on = k * 64 + lane < total;
+        const int x = (int)(mine[k] & 0xffffu), y = (int)(mine[k] >> 16);
+        ymax = on && y > ymax ? y : ymax;
+        xmn = on && x < xmn ? x : xmn, xmx = on && x > xmx ? x : xmx;
+    }
     ymax = (int)wave_max_u32((unsigned)ymax);
+    xmx = (int)wave_max_u32((unsigned)xmx);
+    xmn = w - (int)wave_max_u32((unsigned)(w - xmn));
+    if (total == 0) xmn = 0, xmx = 0;
+    // the live-pixel bitmap covers the points' rows and the 32-bit words of their column range only
+    const int wlo = xmn >> 5, wpr = (xmx >> 5) - wlo + 1, xlo = wlo << 5, xhi = xlo + (wpr << 5);
     if ((ymax - ymin + 1) * wpr > HS_BMW || cfg.line_gap < 1) {
         give_up();
         return;
     }
     if (lane == 0) sh_head = 0, sh_tail = 0, sh_count = total;
     lds_order();
-    int xmn = w, xmx = 0;
 #pragma unroll
     for (int k = 0; k < NZ_PER; ++k) {
         const int i = k * 64 + lane;
@@ -2270,30 +2289,26 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
             const unsigned p = mine[k];
             nz[i] = p;
             const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
-            atomicOr(&bm[(y - ymin) * wpr + (x >> 5)], 1u << (x & 31));
-            xmn = x < xmn ? x : xmn, xmx = x > xmx ? x : xmx;
+            atomicOr(&bm[(y - ymin) * wpr + ((x - xlo) >> 5)], 1u << (x & 31));
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const int a = __shfl_xor(xmn, off, 64), b = __shfl_xor(xmx, off, 64);
-        xmn = a < xmn ? a : xmn, xmx = b > xmx ? b : xmx;
-    }
     lds_order();
+    auto bm_word = [&](int x, int y) -> unsigned* { return &bm[(y - ymin) * wpr + ((x - xlo) >> 5)]; };
     auto live = [&](int x, int y) -> bool {
-        return y >= ymin && y <= ymax && x >= 0 && x < w && ((bm[(y - ymin) * wpr + (x >> 5)] >> (x & 31)) & 1u);
+        return y >= ymin && y <= ymax && x >= xlo && x < xhi && ((*bm_word(x, y) >> (x & 31)) & 1u);
     };
-    const int th = lane * HG + g;
-    const bool th_on = th < NUMANGLE;
+    // lane = (theta row tl, point slot sub): lanes 0 .. 59; theta = HG * tl + g
+    const int sub = lane / HTL, tl = lane - sub * HTL;
+    const int th = tl * HG + g;
+    const bool th_on = sub < HNS && th < NUMANGLE;
     const float ct = th_on ? trig[2 * th] : 0.f, sn = th_on ? trig[2 * th + 1] : 0.f;
-    // this lane's accumulator row: the rho range of the points' bounding box for its theta (+-2 bins).  The
-    // capacity verdict has to be the same in all HG workgroups of the frame, so each one sizes every theta subset.
-    int my_lo = 0, my_base = 0;
-    bool too_big = false;
-    if (wv == 0) {                                  // (the sizing goes through row_sz in LDS: one wave only, result published below)
+    // the accumulator rows: the rho range of the points' bounding box for every theta (+-2 bins).  The capacity verdict has to be
+    // the same in all HG workgroups of the frame, so each one sizes every shard's twelve rows.
+    if (wv == 0) {                                  // (the sizing goes through LDS: one wave only, result published below)
         const int half = (numrho - 1) / 2;
-        int my_tot = 0;
-        for (int gg = 0; gg < HG; ++gg) {
-            const int t2 = lane * HG + gg;
+        int lo_mine = 0;
+        for (int t0 = 0; t0 < HG * HTL; t0 += 64) {
+            const int t2 = t0 + lane;                                 // theta
             int lo = 0, hi = -1;
             if (t2 < NUMANGLE) {
                 const float c2 = trig[2 * t2], s2 = trig[2 * t2 + 1];
@@ -2303,21 +2318,28 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
                 hi = __float2int_rn(fmaxf(fmaxf(r0, r1), fmaxf(r2, r3))) + 2;
                 lo = lo < -half ? -half : lo, hi = hi > half ? half : hi;
             }
-            lds_order();
-            row_sz[lane] = hi - lo + 1;
-            lds_order();
-            int tot = 0, base = 0;
-            for (int n = 0; n < 64; ++n) {
-                if (n == lane) base = tot;
-                tot += row_sz[n];
-            }
-            too_big = too_big || tot > 2 * HS_ACCW;
-            if (gg == g) my_lo = lo, my_base = base, my_tot = tot;
+            if (t2 < HG * HTL) row_sz[t2] = hi - lo + 1;
         }
-        if (!th_on) my_lo = 0, my_base = 0;            // idle lanes read cell 0 (they add 0)
-        (void)my_tot;
-        sh_off[lane] = my_base - my_lo;
-        if (lane == 0) sh_big = too_big ? 1 : 0;
+        lds_order();
+        // lane gg < HG: the cells shard gg needs; every lane: the base of its own row inside shard g
+        bool too_big = false;
+        if (lane < HG) {
+            int tot = 0;
+            for (int q = 0; q < HTL; ++q) tot += row_sz[q * HG + lane];
+            too_big = tot > 2 * HS_ACCW;
+        }
+        int my_base = 0;
+        for (int q = 0; q < tl; ++q) my_base += row_sz[q * HG + g];
+        {
+            const float r0 = (float)xmn * ct + (float)ymin * sn, r1 = (float)xmn * ct + (float)ymax * sn;
+            const float r2 = (float)xmx * ct + (float)ymin * sn, r3 = (float)xmx * ct + (float)ymax * sn;
+            lo_mine = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
+            lo_mine = lo_mine < -half ? -half : lo_mine;
+        }
+        if (!th_on) lo_mine = 0, my_base = 0;          // idle lanes read cell 0 (they add 0)
+        sh_off[lane] = my_base - lo_mine;
+        const unsigned long long bigm = __ballot(too_big);
+        if (lane == 0) sh_big = bigm != 0ull ? 1 : 0;
     }
     __syncthreads();                               // set-up complete in both waves, sizing published
     if (sh_big) {
@@ -2333,19 +2355,20 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         return (int)((old >> sh) & 0xFFFFu) - (int)HS_BIAS;
     };
     auto unvote = [&](int B) { atomicSub(&acc[B >> 1], 1u << ((B & 1) * 16)); };
-    // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope
+    // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope.  Lane k < HG polls partner k;
+    // the sixteen payloads are combined by the caller (OR of hit masks / maximum of keys)
     unsigned seq = 0;
-    auto exchange = [&](int round, unsigned payload, unsigned (&got)[HG]) -> bool {
+    auto exchange = [&](int round, unsigned payload, unsigned& mine_of_partner) -> bool {
         unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
-        unsigned long long wv = ((unsigned long long)seq << 32) | payload;
+        unsigned long long wd = ((unsigned long long)seq << 32) | payload;
         const bool dropped = s == drop_frame && g == HG - 1 && seq == 1u && round == 0;
-        if (lane == 0 && !dropped) __hip_atomic_store(slot + g, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !dropped) __hip_atomic_store(slot + g, wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true;
         if (lane < HG && lane != g) {
             int it = 0;
             for (;;) {
-                wv = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(wv >> 32) == seq) break;
+                wd = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(wd >> 32) == seq) break;
                 if (++it > spin_limit) {
                     ok = false;
                     break;
@@ -2354,8 +2377,7 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
             }
         }
         if (__ballot(!ok) != 0ull) return false;
-#pragma unroll
-        for (int k = 0; k < HG; ++k) got[k] = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)wv, k);
+        mine_of_partner = lane < HG ? (unsigned)wd : 0u;          // (lane g holds its own payload)
         return true;
     };
     int nlines = 0;
@@ -2398,7 +2420,9 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         lds_order();
     };
     // ---- the direction-k half of a fired line's erase: clear its live pixels, and for a good line take their votes back -----------
-    // (direction 1 starts behind the fired pixel itself: direction 0 erases that one)
+    // (direction 1 starts behind the fired pixel itself: direction 0 erases that one).  All 64 lanes test and clear one walk step
+    // each; the votes of the pixels found live are then taken back five at a time -- point slot `sub` takes the set bits of its own
+    // 13-bit slice of the 64-step word, its twelve theta rows each decrementing their cell (decrements commute: any order).
     auto erase_dir = [&](int k) {
         const int x0 = sh_er[0], y0 = sh_er[1], dx0 = sh_er[2], dy0 = sh_er[3], xflag = sh_er[4], good = sh_er[5], tend = sh_er[6 + k];
         const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
@@ -2408,16 +2432,17 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
             int i1, j1;
             if (xflag) j1 = x, i1 = y >> 16; else j1 = x >> 16, i1 = y;
             const bool on = t <= tend && t >= k && live(j1, i1);
-            unsigned long long bits = __ballot(on);
-            if (on) atomicAnd(&bm[(i1 - ymin) * wpr + (j1 >> 5)], ~(1u << (j1 & 31)));
-            if (good) {
-                const float fj = (float)j1, fi = (float)i1;
-                while (bits) {
-                    const int q = __ffsll((long long)bits) - 1;
-                    bits &= bits - 1;
-                    const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fj), q));
-                    const float bi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fi), q));
-                    if (th_on) unvote(cellf(bj, bi));
+            const unsigned long long bits = __ballot(on);
+            if (on) atomicAnd(bm_word(j1, i1), ~(1u << (j1 & 31)));
+            if (good && bits != 0ull) {
+                unsigned mb = sub < HNS ? (unsigned)(bits >> (13 * sub)) & 0x1FFFu : 0u;
+                while (mb) {
+                    const int q = 13 * sub + __ffs((int)mb) - 1;
+                    mb &= mb - 1;
+                    const int tt = t0 + q, xx = x0 + tt * dx, yy = y0 + tt * dy;
+                    int ii, jj;
+                    if (xflag) jj = xx, ii = yy >> 16; else jj = xx >> 16, ii = yy;
+                    if (th_on) unvote(cellf((float)jj, (float)ii));
                 }
             }
             lds_order();
@@ -2473,49 +2498,55 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         const int nb = sh_nb;
         if (nb == 0) break;
         command(CMD_TOPUP);                        // the helper refills the FIFO while this wave votes
-        // ---- speculative votes (LDS returning atomics, in order per lane) ---------------------------------------
-        int val[HB], cel[HB];
+        // ---- speculative votes: instruction v casts the votes of batch points 5 v .. 5 v + 4 (lane = (row tl, slot sub)) --------
+        int val[HNV], cel[HNV];
+        unsigned hm = 0;                                 // per lane: its points whose count reached the threshold here (bit = batch index)
 #pragma unroll
-        for (int b = 0; b < HB; ++b) cel[b] = cellf(bfx[b < nb ? b : 0], bfy[b < nb ? b : 0]);
+        for (int v = 0; v < HNV; ++v) {
+            const int b = v * HNS + sub;
+            const bool bon = th_on && b < nb;
+            cel[v] = cellf(bfx[b < HB ? b : 0], bfy[b < HB ? b : 0]);
+            if (!bon) cel[v] = 0;
+        }
 #pragma unroll
-        for (int b = 0; b < HB; ++b) val[b] = vote(cel[b], (b < nb && th_on) ? 1u : 0u);
-        unsigned hm = 0;                                 // per lane: the points whose count reached the threshold here
-#pragma unroll
-        for (int b = 0; b < HB; ++b) hm |= val[b] + 1 >= cfg.threshold ? 1u << b : 0u;
-        hm = th_on ? hm & (nb == HB ? ~0u : (1u << nb) - 1u) : 0u;
-        const unsigned hitbits = wave_or_u32(hm);          // (one ballot per point instead: 0.514 against 0.471 ms -- 32 dependent scalar tests)
+        for (int v = 0; v < HNV; ++v) {
+            const int b = v * HNS + sub;
+            const bool bon = th_on && b < nb;
+            val[v] = vote(cel[v], bon ? 1u : 0u);
+            hm |= (bon && val[v] + 1 >= cfg.threshold) ? 1u << (b & 31) : 0u;
+        }
+        const unsigned hitbits = wave_or_u32(hm);
         join();
         seq += 1;
-        unsigned got[HG];
+        unsigned got;
         if (!exchange(0, hitbits, got)) {
             give_up();
             finish();
             return;
         }
-        unsigned hits = 0;
-#pragma unroll
-        for (int k = 0; k < HG; ++k) hits |= got[k];
+        const unsigned hits = wave_or_u32(got);
         if (hits == 0) continue;
         const int bs = __ffs((int)hits) - 1;
+        const int bsv = bs / HNS, bss = bs - bsv * HNS;
         int kv = 0;
 #pragma unroll
-        for (int b = 0; b < HB; ++b)
-            if (b == bs) kv = val[b] + 1;
+        for (int v = 0; v < HNV; ++v)
+            if (v == bsv) kv = val[v] + 1;
         // counts can be negative (pixels erased before they voted): order-preserving signed -> unsigned map, 0 = no theta here
-        const unsigned mykey = th_on ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
+        const unsigned mykey = (th_on && sub == bss) ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
         const unsigned lbest = wave_max_u32(mykey);
         // the votes of the points after bs are withdrawn; they are re-examined after the line is erased
 #pragma unroll
-        for (int b = 0; b < HB; ++b)
-            if (b > bs && b < nb && th_on) unvote(cel[b]);
+        for (int v = 0; v < HNV; ++v) {
+            const int b = v * HNS + sub;
+            if (b > bs && b < nb && th_on) unvote(cel[v]);
+        }
         if (!exchange(1, lbest, got)) {
             give_up();
             finish();
             return;
         }
-        unsigned best = 0;
-#pragma unroll
-        for (int k = 0; k < HG; ++k) best = got[k] > best ? got[k] : best;
+        unsigned best = wave_max_u32(got);
         best ^= 0x80000000u;
         if (lane == 0) {
             int head = sh_head;
@@ -2994,7 +3025,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         const char* e = getenv("AVHOT_HOUGH_SHARD");
         const bool use_shard = !(e && atoi(e) == 0);
         if (use_shard) {
-            hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 32 + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
+            hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 8 * HG + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
             AV_LAUNCH_CHECK();
             const char* sp = getenv("AVHOT_HOUGH_SPIN");
             const char* dr = getenv("AVHOT_HOUGH_DROP");
