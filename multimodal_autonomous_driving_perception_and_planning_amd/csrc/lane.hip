@@ -2157,35 +2157,39 @@ __global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, Hou
     if (tid == 0) nseg[s] = nlines;
 }
 
-// ---- L4b': PPHT with theta sharded over HG workgroups per frame, accumulator in LDS ------------------------------
+// ---- L4b': PPHT with theta sharded over workgroups AND waves, accumulator in LDS ---------------------------------------
 // houghp_fast is bound by its CU's L1/TA pipeline: every theta lane votes into its own 16-KB row of a global
-// accumulator, one cache line per lane per vote.  Here a frame is handled by HG = 16 workgroups (a main wave + a helper wave each,
-// see the kernel); workgroup g owns theta = HG * tl + g, tl = 0 .. 11, and keeps ONLY those twelve rows, in LDS, over the rho range
-// the points' bounding box can reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed two to a word (PPHT's
-// erase also decrements pixels that have not voted yet, so counts go negative; |count| <= number of points <= 4096).  Every
-// workgroup replays the same point list, RNG, FIFO, bitmap and line walks -- all deterministic -- so they stay
-// in step by construction and exchange just two words per batch through global memory: the mask of batch points
-// whose vote reached the threshold, and, when a line fires, their best (count, theta) key.  A word carries its
-// batch sequence number and is stored/loaded with agent scope (the XCDs' L2s are not coherent); slots are double-
-// buffered by sequence parity; every spin is bounded and a timeout hands the frame to houghp_fast.
+// accumulator, one cache line per lane per vote.  Here a frame is handled by HG = 4 workgroups of HVW = 4 voting waves (+ a helper
+// wave): voting wave v of workgroup g is sub-shard q = 4 g + v of 16 and owns theta = 16 tl + q, tl = 0 .. 11 -- twelve rows, kept in
+// LDS over the rho range the points' bounding box can reach (variable-length rows), as 16-bit counters biased by 0x4000 and packed
+// two to a word (PPHT's erase also decrements pixels that have not voted yet, so counts go negative; |count| <= number of points
+// <= 4096).  A workgroup keeps ONE copy of the point list, RNG position, FIFO and live-pixel bitmap and replays the sequential
+// part of the algorithm once (wave 0: batch forming, line walk; helper wave: FIFO top-ups, the second direction of every erase);
+// the four workgroups of a frame replay it identically -- all deterministic -- so they stay in step by construction and exchange
+// just two words per batch through global memory: the mask of batch points whose vote reached the threshold, and, when a line
+// fires, their best (count, theta) key.  A word carries its batch sequence number and is stored/loaded with agent scope (the XCDs'
+// L2s are not coherent); slots are double-buffered by sequence parity; every spin is bounded and a timeout hands the frame to
+// houghp_fast.  Inside a workgroup the waves meet at workgroup barriers (phases below) and pass masks / keys through LDS.
 //
-// Round 4: sixteen shards of twelve rows instead of four of forty-five, for two reasons.
-//  * LDS: 79 KB per workgroup (accumulator 24 KB, point list 16 KB, live-pixel bitmap over the points' column range 36 KB) instead of
-//    158 KB -- two workgroups per CU, or one beside a convolution workgroup of the detector (config 3 runs the lane chain beside it;
-//    the 158-KB claim kept every LDS-tiled convolution off the CUs it ran on).  A frame's shards need not all be resident at once
-//    for progress: workgroups are dispatched in blockIdx order, so the frames in front complete and make room; a shard whose
-//    partners are still waiting for a slot just spins (bounded).
-//  * votes: a lane is (theta row tl, point slot sub) -- 12 x 5 = 60 lanes -- and ONE returning LDS atomic instruction casts the votes
-//    of five consecutive batch points: a batch of 32 is 7 instructions instead of 32.  A vote's returned count must include exactly
-//    the batch's EARLIER points on the same cell; the points of one instruction that hit the same cell sit in lanes tl, tl + 12,
-//    tl + 24, ... in batch order, and the LDS serves the lanes of one atomic instruction that address the same word in increasing
-//    lane order, each with the running value (tools/wldsorder.hip: 0 violations in 4 x 65 536 lanes over all-same, paired,
-//    quadruple and random address patterns, with and without a second wave hammering the same banks).
-constexpr int HG = 16, HTL = 12, HNS = 5, HNV = (HB + HNS - 1) / HNS;    // shards, theta rows per shard, point slots per instruction, vote instructions per batch
-constexpr int HS_NZ = 4096, HS_BMW = 9216, HS_ACCW = 6144;        // LDS capacities: points, bitmap words (288 rows x 32 words), accumulator words
+// Round 4: the votes.  Round 3 had one voting wave per workgroup, lane = theta row (45 of 64 lanes), one returning LDS atomic per
+// batch point: 32 dependent-issue instructions per batch on a lone wave, 47 % of the kernel.  Now a voting lane is (theta row tl,
+// point slot sub) -- 12 x 5 = 60 lanes -- and ONE returning atomic instruction casts the votes of five consecutive batch points on
+// twelve rows: a batch of 32 is 7 instructions per wave, on four waves side by side.  A vote's returned count must include exactly
+// the batch's EARLIER points on the same cell; the points of one instruction that hit the same cell sit in lanes tl, tl + 12,
+// tl + 24, ... in batch order, and the LDS serves the lanes of one atomic instruction that address the same word in increasing lane
+// order, each with the running value (tools/wldsorder.hip: 0 violations in 4 x 65 536 lanes over all-same, paired, quadruple and
+// random address patterns, with and without a second wave hammering the same banks); rows of different waves are disjoint, so
+// the waves need no order among themselves.  (Round 3 had tried two waves voting halves of a batch on the SAME rows: one run in
+// five lost or gained a segment.)  Sixteen single-wave shards in sixteen workgroups of 79 KB -- two per CU, or one beside a
+// convolution workgroup -- were built first: same segments, but 1 024 workgroups are two rounds of residency on 256 CUs, 422 us
+// per 64 frames against 277; the replicated point list + bitmap (52 KB) are what keeps a finer split from fitting.
+constexpr int HG = 4, HVW = 4, HQ = HG * HVW, HTL = 12, HNS = 5, HNV = (HB + HNS - 1) / HNS;    // workgroups per frame, voting waves, sub-shards,
+                                                                  // theta rows per sub-shard, point slots per instruction, vote instructions per batch
+constexpr int HS_NZ = 4096, HS_BMW = 9216, HS_ACCW = 6144;        // LDS capacities: points, bitmap words (288 rows x 32 words), accumulator words per voting wave
+constexpr int HS_EB = 48;                                         // 64-step words of one direction of a line walk (3 072 steps)
 constexpr unsigned HS_BIAS = 0x4000u;
 constexpr int HS_SPIN = 1 << 20;              // default bound of every exchange spin (x s_sleep 2), ~0.1 s; AVHOT_HOUGH_SPIN overrides it
-static_assert(HG * HTL >= NUMANGLE && HTL * HNS <= 64 && HG <= 64, "shard geometry");
+static_assert(HQ * HTL >= NUMANGLE && HTL * HNS <= 64 && HG <= 64, "shard geometry");
 
 __global__ void hough_prep_kernel(int n_streams, int numrho, int* __restrict__ accum_all, int* __restrict__ fallback) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2209,66 +2213,61 @@ constexpr HoughDraws hough_draws() {
 }
 __device__ const HoughDraws g_draws = hough_draws();
 
-__global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
+__global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int numrho, HoughCfg cfg, const unsigned* __restrict__ nz_all,
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
                                                    int* __restrict__ nseg, int* __restrict__ fallback, int spin_limit,
                                                    int drop_frame, int* __restrict__ path) {
     // spin_limit: iterations an exchange waits for a partner before the frame is handed to houghp_fast; drop_frame (tests only,
-    // AVHOT_HOUGH_DROP): shard HG-1 of that frame never publishes its first exchange word, so its partners run into the limit
-    __shared__ unsigned acc[HS_ACCW];
+    // AVHOT_HOUGH_DROP): workgroup HG-1 of that frame never publishes its first exchange word, so its partners run into the limit
+    __shared__ unsigned acc_all[HVW][HS_ACCW];
     __shared__ unsigned nz[HS_NZ];
     __shared__ unsigned bm[HS_BMW];
     __shared__ int fifo[FIFO];
     __shared__ int bpt[HB];
     __shared__ float bfx[HB], bfy[HB];
-    __shared__ int row_sz[HG * HTL];
-    __shared__ int sh_nb, sh_head, sh_tail, sh_count;
-    // Second wave = helper.  A lone wave issues one instruction per 5-8 cycles however independent they are (tools/wvalu.hip).  The
-    // helper wave (on another SIMD) runs every FIFO top-up -- beside the votes and the exchange of the same batch -- and the second
-    // direction of every erase; it follows the main wave through a command word in LDS and a pair of workgroup barriers per command.
-    __shared__ int sh_cmd, sh_er[12], sh_off[64], sh_big;
-    enum { CMD_EXIT = 0, CMD_TOPUP = 1, CMD_ERASE = 2 };
+    __shared__ int row_sz[HQ * HTL];
+    __shared__ unsigned long long ebits[2][HS_EB];             // live pixels found (and cleared) by the two directions of an erase
+    __shared__ unsigned sh_hit[HVW], sh_key[HVW];
+    __shared__ int sh_nb, sh_head, sh_tail, sh_count, sh_big, sh_hits, sh_fail, sh_er[8];
     const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);       // 0 .. HVW-1: voting waves (0 also runs the sequential part); HVW: helper
+    const bool voter = wv < HVW;
     const unsigned* nzg = nz_all + (size_t)s * h * w;
     unsigned long long* xw = reinterpret_cast<unsigned long long*>(accum_all + (size_t)s * NUMANGLE * numrho);
     const int total = npts[s];
     auto give_up = [&]() {
-        if (lane == 0) fallback[s] = 1;
+        if (wv == 0 && lane == 0) fallback[s] = 1;
     };
     auto lds_order = [&]() {                       // one wave: order its LDS writes before later reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
+    constexpr int NTH = (HVW + 1) * 64;
     // the LDS clears do not depend on the point list: they run while its loads are in flight
-    for (int i = (int)threadIdx.x; i < HS_ACCW; i += 128) acc[i] = HS_BIAS | (HS_BIAS << 16);
-    for (int i = (int)threadIdx.x; i < HS_BMW; i += 128) bm[i] = 0;
-    if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups (and both waves)
+    for (int i = (int)threadIdx.x; i < HVW * HS_ACCW; i += NTH) (&acc_all[0][0])[i] = HS_BIAS | (HS_BIAS << 16);
+    for (int i = (int)threadIdx.x; i < HS_BMW; i += NTH) bm[i] = 0;
+    if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups (and every wave)
         give_up();
         return;
     }
-    __syncthreads();                               // the clears are shared between the waves: done before either fills the bitmap
-    // (both waves run the set-up below -- same loads, same LDS writes of the same values, same verdicts -- so the helper has the
-    // frame's constants in its own registers; the first barrier comes behind it)
-    auto command = [&](int cmd) {                  // main wave: start the helper on `cmd` (LDS state published by the barrier)
-        if (lane == 0) sh_cmd = cmd;
-        __syncthreads();
-    };
-    auto finish = [&]() { command(CMD_EXIT); };   // main wave: every way out of the kernel releases the helper
+    // ---- set-up: bounding box of the points (every wave computes it: same loads, same verdicts), list + bitmap into LDS -------
     constexpr int NZ_PER = HS_NZ / 64;
-    unsigned mine[NZ_PER];
-#pragma unroll
-    for (int k = 0; k < NZ_PER; ++k) mine[k] = k * 64 + lane < total ? nzg[k * 64 + lane] : 0u;
-    const int ymin = total > 0 ? (int)((unsigned)__builtin_amdgcn_readfirstlane((int)mine[0]) >> 16) : 0;
     int ymax = 0, xmn = w, xmx = 0;                                                       // the list is sorted by (y, x)
-#pragma unroll
-    for (int k = 0; k < NZ_PER; ++k) {
-        const bool on = k * 64 + lane < total;
-        const int x = (int)(mine[k] & 0xffffu), y = (int)(mine[k] >> 16);
-        ymax = on && y > ymax ? y : ymax;
-        xmn = on && x < xmn ? x : xmn, xmx = on && x > xmx ? x : xmx;
+    int ymin = 0;
+    {
+        unsigned first = 0;
+#pragma unroll 8
+        for (int k = 0; k < NZ_PER; ++k) {
+            const bool on = k * 64 + lane < total;
+            const unsigned p = on ? nzg[k * 64 + lane] : 0u;
+            if (k == 0) first = p;
+            const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+            ymax = on && y > ymax ? y : ymax;
+            xmn = on && x < xmn ? x : xmn, xmx = on && x > xmx ? x : xmx;
+        }
+        ymin = total > 0 ? (int)((unsigned)__builtin_amdgcn_readfirstlane((int)first) >> 16) : 0;
     }
     ymax = (int)wave_max_u32((unsigned)ymax);
     xmx = (int)wave_max_u32((unsigned)xmx);
@@ -2280,74 +2279,64 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         give_up();
         return;
     }
-    if (lane == 0) sh_head = 0, sh_tail = 0, sh_count = total;
-    lds_order();
-#pragma unroll
-    for (int k = 0; k < NZ_PER; ++k) {
-        const int i = k * 64 + lane;
-        if (i < total) {
-            const unsigned p = mine[k];
-            nz[i] = p;
-            const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
-            atomicOr(&bm[(y - ymin) * wpr + ((x - xlo) >> 5)], 1u << (x & 31));
-        }
+    __syncthreads();                               // the clears are done before anybody fills the bitmap
+    for (int i = (int)threadIdx.x; i < total; i += NTH) {
+        const unsigned p = nzg[i];
+        nz[i] = p;
+        const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+        atomicOr(&bm[(y - ymin) * wpr + ((x - xlo) >> 5)], 1u << (x & 31));
     }
-    lds_order();
+    if (threadIdx.x == 0) sh_head = 0, sh_tail = 0, sh_count = total, sh_fail = 0;
     auto bm_word = [&](int x, int y) -> unsigned* { return &bm[(y - ymin) * wpr + ((x - xlo) >> 5)]; };
     auto live = [&](int x, int y) -> bool {
         return y >= ymin && y <= ymax && x >= xlo && x < xhi && ((*bm_word(x, y) >> (x & 31)) & 1u);
     };
-    // lane = (theta row tl, point slot sub): lanes 0 .. 59; theta = HG * tl + g
+    // voting lane = (theta row tl, point slot sub): lanes 0 .. 59; theta = HQ * tl + q, q = HVW * g + wave
     const int sub = lane / HTL, tl = lane - sub * HTL;
-    const int th = tl * HG + g;
-    const bool th_on = sub < HNS && th < NUMANGLE;
+    const int q_mine = g * HVW + (voter ? wv : 0);
+    const int th = tl * HQ + q_mine;
+    const bool th_on = voter && sub < HNS && th < NUMANGLE;
     const float ct = th_on ? trig[2 * th] : 0.f, sn = th_on ? trig[2 * th + 1] : 0.f;
     // the accumulator rows: the rho range of the points' bounding box for every theta (+-2 bins).  The capacity verdict has to be
-    // the same in all HG workgroups of the frame, so each one sizes every shard's twelve rows.
-    if (wv == 0) {                                  // (the sizing goes through LDS: one wave only, result published below)
-        const int half = (numrho - 1) / 2;
-        int lo_mine = 0;
-        for (int t0 = 0; t0 < HG * HTL; t0 += 64) {
-            const int t2 = t0 + lane;                                 // theta
+    // the same in all HG workgroups of the frame, so each one sizes every sub-shard's twelve rows.
+    const int half = (numrho - 1) / 2;
+    auto row_lo_hi = [&](float c2, float s2, int& lo, int& hi) {
+        const float r0 = (float)xmn * c2 + (float)ymin * s2, r1 = (float)xmn * c2 + (float)ymax * s2;
+        const float r2 = (float)xmx * c2 + (float)ymin * s2, r3 = (float)xmx * c2 + (float)ymax * s2;
+        lo = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
+        hi = __float2int_rn(fmaxf(fmaxf(r0, r1), fmaxf(r2, r3))) + 2;
+        lo = lo < -half ? -half : lo, hi = hi > half ? half : hi;
+    };
+    if (wv == 0) {
+        for (int t2 = lane; t2 < HQ * HTL; t2 += 64) {               // t2 = theta
             int lo = 0, hi = -1;
-            if (t2 < NUMANGLE) {
-                const float c2 = trig[2 * t2], s2 = trig[2 * t2 + 1];
-                const float r0 = (float)xmn * c2 + (float)ymin * s2, r1 = (float)xmn * c2 + (float)ymax * s2;
-                const float r2 = (float)xmx * c2 + (float)ymin * s2, r3 = (float)xmx * c2 + (float)ymax * s2;
-                lo = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
-                hi = __float2int_rn(fmaxf(fmaxf(r0, r1), fmaxf(r2, r3))) + 2;
-                lo = lo < -half ? -half : lo, hi = hi > half ? half : hi;
-            }
-            if (t2 < HG * HTL) row_sz[t2] = hi - lo + 1;
+            if (t2 < NUMANGLE) row_lo_hi(trig[2 * t2], trig[2 * t2 + 1], lo, hi);
+            row_sz[t2] = hi - lo + 1;
         }
         lds_order();
-        // lane gg < HG: the cells shard gg needs; every lane: the base of its own row inside shard g
         bool too_big = false;
-        if (lane < HG) {
+        if (lane < HQ) {                                             // lane q: the cells sub-shard q needs
             int tot = 0;
-            for (int q = 0; q < HTL; ++q) tot += row_sz[q * HG + lane];
+            for (int r = 0; r < HTL; ++r) tot += row_sz[r * HQ + lane];
             too_big = tot > 2 * HS_ACCW;
         }
-        int my_base = 0;
-        for (int q = 0; q < tl; ++q) my_base += row_sz[q * HG + g];
-        {
-            const float r0 = (float)xmn * ct + (float)ymin * sn, r1 = (float)xmn * ct + (float)ymax * sn;
-            const float r2 = (float)xmx * ct + (float)ymin * sn, r3 = (float)xmx * ct + (float)ymax * sn;
-            lo_mine = __float2int_rn(fminf(fminf(r0, r1), fminf(r2, r3))) - 2;
-            lo_mine = lo_mine < -half ? -half : lo_mine;
-        }
-        if (!th_on) lo_mine = 0, my_base = 0;          // idle lanes read cell 0 (they add 0)
-        sh_off[lane] = my_base - lo_mine;
         const unsigned long long bigm = __ballot(too_big);
         if (lane == 0) sh_big = bigm != 0ull ? 1 : 0;
     }
-    __syncthreads();                               // set-up complete in both waves, sizing published
+    __syncthreads();                               // list, bitmap, sizes and the verdict are in LDS
     if (sh_big) {
         give_up();
         return;
     }
-    // cell index of (this lane's theta, rho of the pixel); idle lanes have ct = sn = 0 and land on cell 0
-    const int my_off = sh_off[lane];
+    int my_off = 0;
+    if (th_on) {
+        int my_base = 0, lo, hi;
+        for (int r = 0; r < tl; ++r) my_base += row_sz[r * HQ + q_mine];
+        row_lo_hi(ct, sn, lo, hi);
+        my_off = my_base - lo;
+    }
+    unsigned* const acc = acc_all[voter ? wv : 0];
+    // cell index of (this lane's theta, rho of the pixel); idle lanes have ct = sn = 0, my_off = 0 and land on cell 0 (they add 0)
     auto cellf = [&](float fx, float fy) { return __float2int_rn(fx * ct + fy * sn) + my_off; };
     auto vote = [&](int B, unsigned add) -> int {          // count BEFORE the vote (add = 0: a plain read)
         const int sh = (B & 1) * 16;
@@ -2355,10 +2344,10 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         return (int)((old >> sh) & 0xFFFFu) - (int)HS_BIAS;
     };
     auto unvote = [&](int B) { atomicSub(&acc[B >> 1], 1u << ((B & 1) * 16)); };
-    // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope.  Lane k < HG polls partner k;
-    // the sixteen payloads are combined by the caller (OR of hit masks / maximum of keys)
+    // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope.  Wave 0 only; lane k < HG
+    // polls partner k; the payloads are combined by the caller (OR of hit masks / maximum of keys)
     unsigned seq = 0;
-    auto exchange = [&](int round, unsigned payload, unsigned& mine_of_partner) -> bool {
+    auto exchange = [&](int round, unsigned payload, unsigned& of_partner) -> bool {
         unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
         unsigned long long wd = ((unsigned long long)seq << 32) | payload;
         const bool dropped = s == drop_frame && g == HG - 1 && seq == 1u && round == 0;
@@ -2377,23 +2366,26 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
             }
         }
         if (__ballot(!ok) != 0ull) return false;
-        mine_of_partner = lane < HG ? (unsigned)wd : 0u;          // (lane g holds its own payload)
+        of_partner = lane < HG ? (unsigned)wd : 0u;                 // (lane g holds its own payload)
         return true;
     };
-    int nlines = 0;
     const int shift = 16;
     const int kk = lane & (HB - 1);                 // both half-waves work on draw kk of a top-up
-    unsigned r_next = kk < total ? g_draws.v[kk] : 0u;
-    auto top_up = [&]() {
+    // FIFO top-up (one wave; normally the helper, beside the votes of the batch just formed).  The draws are a function of how many
+    // points were drawn before (cv::RNG(-1) per call: a compile-time table); the helper keeps the next top-up's draws in flight.
+    int pre_base = -1;
+    unsigned pre_r = 0;
+    auto top_up = [&](bool prefetch) {
         const int cnt = sh_count, fill = sh_tail - sh_head;
         int nd = FIFO - HB - fill;
         nd = nd < HB ? nd : HB;
         nd = nd < cnt ? nd : cnt;
         if (nd <= 0) return;
-        const unsigned r_mine = r_next;
-        {                                              // the next top-up's draws, in flight until then
-            const int nxt = total - cnt + nd + kk;
-            r_next = nxt < total ? g_draws.v[nxt] : 0u;
+        const int base = total - cnt;
+        const unsigned r_mine = pre_base == base ? pre_r : (base + kk < total ? g_draws.v[base + kk] : 0u);
+        if (prefetch) {
+            pre_base = base + nd;
+            pre_r = pre_base + kk < total ? g_draws.v[pre_base + kk] : 0u;
         }
         // cv's draw: step k takes nz[idx_k] and moves nz[cnt-1-k] into its place -- a chain when replayed literally.
         // Resolved in registers instead: what position p holds at step k is what the ORIGINAL array holds at the
@@ -2419,14 +2411,12 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
         if (lane == 0) sh_tail = sh_tail + nd, sh_count = cnt - nd;
         lds_order();
     };
-    // ---- the direction-k half of a fired line's erase: clear its live pixels, and for a good line take their votes back -----------
-    // (direction 1 starts behind the fired pixel itself: direction 0 erases that one).  All 64 lanes test and clear one walk step
-    // each; the votes of the pixels found live are then taken back five at a time -- point slot `sub` takes the set bits of its own
-    // 13-bit slice of the 64-step word, its twelve theta rows each decrementing their cell (decrements commute: any order).
-    auto erase_dir = [&](int k) {
-        const int x0 = sh_er[0], y0 = sh_er[1], dx0 = sh_er[2], dy0 = sh_er[3], xflag = sh_er[4], good = sh_er[5], tend = sh_er[6 + k];
+    // ---- the direction-k half of a fired line's erase, bitmap part (one wave): test and clear the live pixels of the walk, 64 steps
+    // per trip, and leave the found bits for the voting waves (direction 1 starts behind the fired pixel: direction 0 erases that one)
+    auto erase_bitmap = [&](int k) {
+        const int x0 = sh_er[0], y0 = sh_er[1], dx0 = sh_er[2], dy0 = sh_er[3], xflag = sh_er[4], tend = sh_er[6 + k];
         const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-        for (int t0 = 0; t0 <= tend; t0 += 64) {
+        for (int t0 = 0, c = 0; t0 <= tend; t0 += 64, ++c) {
             const int t = t0 + lane;
             const int x = x0 + t * dx, y = y0 + t * dy;
             int i1, j1;
@@ -2434,7 +2424,19 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
             const bool on = t <= tend && t >= k && live(j1, i1);
             const unsigned long long bits = __ballot(on);
             if (on) atomicAnd(bm_word(j1, i1), ~(1u << (j1 & 31)));
-            if (good && bits != 0ull) {
+            if (lane == 0) ebits[k][c] = bits;
+            lds_order();
+        }
+    };
+    // ... and the accumulator part (every voting wave, its own rows): the votes of the pixels found live are taken back five at a
+    // time -- point slot `sub` takes the set bits of its own 13-bit slice of a 64-step word (decrements commute: any order)
+    auto erase_votes = [&]() {
+        const int x0 = sh_er[0], y0 = sh_er[1], dx0 = sh_er[2], dy0 = sh_er[3], xflag = sh_er[4];
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0, tend = sh_er[6 + k];
+            for (int t0 = 0, c = 0; t0 <= tend; t0 += 64, ++c) {
+                const unsigned long long bits = ebits[k][c];
+                if (bits == 0ull) continue;
                 unsigned mb = sub < HNS ? (unsigned)(bits >> (13 * sub)) & 0x1FFFu : 0u;
                 while (mb) {
                     const int q = 13 * sub + __ffs((int)mb) - 1;
@@ -2445,26 +2447,15 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
                     if (th_on) unvote(cellf((float)jj, (float)ii));
                 }
             }
-            lds_order();
         }
     };
-    if (wv == 1) {
-        for (;;) {
-            __syncthreads();                       // a command is published
-            const int cmd = sh_cmd;
-            if (cmd == CMD_EXIT) break;
-            if (cmd == CMD_TOPUP) top_up();
-            else erase_dir(1);
-            __syncthreads();                       // done
-        }
-        return;
-    }
-    auto join = [&]() { __syncthreads(); };       // main wave: the helper's command is done
-    command(CMD_TOPUP);
-    join();
+    int nlines = 0;
+    if (wv == HVW) top_up(true);
+    __syncthreads();
+    // Phases of one batch; every wave passes the same barriers (B1 .. B6), all tests between them are workgroup-uniform (LDS words).
     for (;;) {
-        // ---- form the batch: pop up to HB points that are still live ---------------------------------------------
-        {
+        // ---- wave 0: form the batch: pop up to HB points that are still live ------------------------------------------------------
+        if (wv == 0) {
             int head = sh_head;
             int nb = 0;
             for (;;) {
@@ -2472,8 +2463,8 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
                 if (avail == 0) {
                     if (sh_count == 0) break;
                     if (lane == 0) sh_head = head;
-                    command(CMD_TOPUP);            // (rare: the FIFO ran dry inside a batch)
-                    join();
+                    lds_order();
+                    top_up(false);                 // (rare: the FIFO ran dry inside a batch -- the helper is idle in this phase)
                     continue;
                 }
                 const int take = avail < (HB - nb) ? avail : (HB - nb);
@@ -2493,152 +2484,175 @@ __global__ void __launch_bounds__(128) houghp_shard(int h, int w, int numrho, Ho
                 if (nb == HB) break;
             }
             if (lane == 0) sh_head = head, sh_nb = nb;
-            lds_order();
         }
+        __syncthreads();                           // B1: the batch is in LDS
         const int nb = sh_nb;
         if (nb == 0) break;
-        command(CMD_TOPUP);                        // the helper refills the FIFO while this wave votes
-        // ---- speculative votes: instruction v casts the votes of batch points 5 v .. 5 v + 4 (lane = (row tl, slot sub)) --------
+        // ---- voting waves: speculative votes, instruction v = batch points 5 v .. 5 v + 4; helper: the next top-up ---------------
         int val[HNV], cel[HNV];
-        unsigned hm = 0;                                 // per lane: its points whose count reached the threshold here (bit = batch index)
+        if (voter) {
+            unsigned hm = 0;                             // per lane: its points whose count reached the threshold here (bit = batch index)
 #pragma unroll
-        for (int v = 0; v < HNV; ++v) {
-            const int b = v * HNS + sub;
-            const bool bon = th_on && b < nb;
-            cel[v] = cellf(bfx[b < HB ? b : 0], bfy[b < HB ? b : 0]);
-            if (!bon) cel[v] = 0;
-        }
+            for (int v = 0; v < HNV; ++v) {
+                const int b = v * HNS + sub;
+                const bool bon = th_on && b < nb;
+                cel[v] = bon ? cellf(bfx[b < HB ? b : 0], bfy[b < HB ? b : 0]) : 0;
+            }
 #pragma unroll
-        for (int v = 0; v < HNV; ++v) {
-            const int b = v * HNS + sub;
-            const bool bon = th_on && b < nb;
-            val[v] = vote(cel[v], bon ? 1u : 0u);
-            hm |= (bon && val[v] + 1 >= cfg.threshold) ? 1u << (b & 31) : 0u;
+            for (int v = 0; v < HNV; ++v) {
+                const int b = v * HNS + sub;
+                const bool bon = th_on && b < nb;
+                val[v] = vote(cel[v], bon ? 1u : 0u);
+                hm |= (bon && val[v] + 1 >= cfg.threshold) ? 1u << (b & 31) : 0u;
+            }
+            const unsigned hb = wave_or_u32(hm);
+            if (lane == 0) sh_hit[wv] = hb;
+        } else {
+            top_up(true);
         }
-        const unsigned hitbits = wave_or_u32(hm);
-        join();
-        seq += 1;
-        unsigned got;
-        if (!exchange(0, hitbits, got)) {
+        __syncthreads();                           // B2: hit masks of the four voting waves, FIFO refilled
+        if (wv == 0) {
+            unsigned hitbits = 0;
+#pragma unroll
+            for (int v = 0; v < HVW; ++v) hitbits |= sh_hit[v];
+            seq += 1;
+            unsigned got = 0;
+            const bool ok = exchange(0, hitbits, got);
+            const unsigned hits = wave_or_u32(got);
+            if (lane == 0) sh_hits = (int)hits, sh_fail = ok ? 0 : 1;
+        }
+        __syncthreads();                           // B3: the frame's hit mask
+        if (sh_fail) {
             give_up();
-            finish();
             return;
         }
-        const unsigned hits = wave_or_u32(got);
+        const unsigned hits = (unsigned)sh_hits;
         if (hits == 0) continue;
         const int bs = __ffs((int)hits) - 1;
-        const int bsv = bs / HNS, bss = bs - bsv * HNS;
-        int kv = 0;
+        if (voter) {
+            const int bsv = bs / HNS, bss = bs - bsv * HNS;
+            int kv = 0;
 #pragma unroll
-        for (int v = 0; v < HNV; ++v)
-            if (v == bsv) kv = val[v] + 1;
-        // counts can be negative (pixels erased before they voted): order-preserving signed -> unsigned map, 0 = no theta here
-        const unsigned mykey = (th_on && sub == bss) ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
-        const unsigned lbest = wave_max_u32(mykey);
-        // the votes of the points after bs are withdrawn; they are re-examined after the line is erased
+            for (int v = 0; v < HNV; ++v)
+                if (v == bsv) kv = val[v] + 1;
+            // counts can be negative (pixels erased before they voted): order-preserving signed -> unsigned map, 0 = no theta here
+            const unsigned mykey = (th_on && sub == bss) ? ((unsigned)((kv << 8) | (255 - th)) ^ 0x80000000u) : 0u;
+            const unsigned lb = wave_max_u32(mykey);
+            if (lane == 0) sh_key[wv] = lb;
+            // the votes of the points after bs are withdrawn; they are re-examined after the line is erased
 #pragma unroll
-        for (int v = 0; v < HNV; ++v) {
-            const int b = v * HNS + sub;
-            if (b > bs && b < nb && th_on) unvote(cel[v]);
+            for (int v = 0; v < HNV; ++v) {
+                const int b = v * HNS + sub;
+                if (b > bs && b < nb && th_on) unvote(cel[v]);
+            }
         }
-        if (!exchange(1, lbest, got)) {
+        __syncthreads();                           // B4: the workgroup's best keys
+        if (wv == 0) {
+            unsigned lbest = 0;
+#pragma unroll
+            for (int v = 0; v < HVW; ++v) lbest = sh_key[v] > lbest ? sh_key[v] : lbest;
+            unsigned got = 0;
+            const bool ok = exchange(1, lbest, got);
+            unsigned best = wave_max_u32(got);
+            best ^= 0x80000000u;
+            if (lane == 0) {
+                int head = sh_head;
+                for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
+                sh_head = head;
+            }
+            lds_order();
+            const int max_n = 255 - (int)(best & 255u);
+            const int j = bpt[bs] & 0xffff, i = bpt[bs] >> 16;
+            // ---- walk along the line in both directions ----------------------------------------------------------
+            const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
+            int x0 = j, y0 = i, dx0, dy0, xflag;
+            if (fabsf(a) > fabsf(b)) {
+                xflag = 1;
+                dx0 = a > 0 ? 1 : -1;
+                dy0 = __float2int_rn(b * (float)(1 << shift) / fabsf(a));
+                y0 = (y0 << shift) + (1 << (shift - 1));
+            } else {
+                xflag = 0;
+                dy0 = b > 0 ? 1 : -1;
+                dx0 = __float2int_rn(a * (float)(1 << shift) / fabsf(b));
+                x0 = (x0 << shift) + (1 << (shift - 1));
+            }
+            int ends[2][3];
+            for (int k = 0; k < 2; ++k) {
+                const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+                int gap = 0, et = 0;
+                bool done = false;
+                for (int t0 = 0; !done; t0 += 64) {
+                    const int t = t0 + lane;
+                    const int x = x0 + t * dx, y = y0 + t * dy;
+                    int i1, j1;
+                    if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
+                    const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
+                    const bool on = inb && live(j1, i1);
+                    const unsigned long long fo = __ballot(on), fi = __ballot(inb);
+                    const int nin = fi == ~0ull ? 64 : __ffsll((long long)~fi) - 1;         // in-bounds steps of this word
+                    int pos = 0;
+                    if (cfg.line_gap >= 63 && nin > 0) {           // no run of zeros inside one word can exceed the gap
+                        const unsigned long long f = nin == 64 ? fo : fo & ((1ull << nin) - 1ull);
+                        if (f == 0ull) {
+                            if (gap + nin > cfg.line_gap) done = true;
+                            gap += nin;
+                        } else if (gap + (__ffsll((long long)f) - 1) > cfg.line_gap) {
+                            done = true;
+                        } else {
+                            const int last = 63 - __clzll((long long)f);
+                            et = t0 + last;
+                            gap = nin - 1 - last;
+                        }
+                        pos = nin;
+                    }
+                    while (pos < nin) {                                                        // the gap rule (line_gap >= 1)
+                        const unsigned long long rest = fo >> pos;
+                        int z = rest == 0ull ? 64 : __ffsll((long long)rest) - 1;            // zeros before the next hit
+                        if (z >= nin - pos) {
+                            const int zeros = nin - pos;
+                            if (gap + zeros > cfg.line_gap) done = true;
+                            gap += zeros;
+                            pos = nin;
+                            break;
+                        }
+                        if (gap + z > cfg.line_gap) { done = true; break; }
+                        pos += z;
+                        gap = 0;
+                        et = t0 + pos;
+                        ++pos;
+                    }
+                    if (nin < 64) done = true;                                                 // left the image
+                }
+                const int xx = x0 + et * dx, yy = y0 + et * dy;
+                ends[k][0] = xflag ? xx : xx >> shift, ends[k][1] = xflag ? yy >> shift : yy, ends[k][2] = et;
+            }
+            const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
+            const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
+            const bool fits = ends[0][2] < 64 * HS_EB && ends[1][2] < 64 * HS_EB;              // (walks longer than the bit buffer: houghp_fast)
+            if (lane == 0) {
+                sh_er[0] = x0, sh_er[1] = y0, sh_er[2] = dx0, sh_er[3] = dy0, sh_er[4] = xflag, sh_er[5] = good ? 1 : 0;
+                sh_er[6] = ends[0][2], sh_er[7] = ends[1][2];
+                sh_fail = (ok && fits) ? 0 : 1;
+                if (good && ok && fits && g == 0) {
+                    int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
+                    o[0] = e0x, o[1] = e0y, o[2] = e1x, o[3] = e1y;
+                }
+            }
+        }
+        __syncthreads();                           // B5: the line
+        if (sh_fail) {
             give_up();
-            finish();
             return;
         }
-        unsigned best = wave_max_u32(got);
-        best ^= 0x80000000u;
-        if (lane == 0) {
-            int head = sh_head;
-            for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
-            sh_head = head;
-        }
-        lds_order();
-        const int max_n = 255 - (int)(best & 255u);
-        const int j = bpt[bs] & 0xffff, i = bpt[bs] >> 16;
-        // ---- walk along the line in both directions --------------------------------------------------------------
-        const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
-        int x0 = j, y0 = i, dx0, dy0, xflag;
-        if (fabsf(a) > fabsf(b)) {
-            xflag = 1;
-            dx0 = a > 0 ? 1 : -1;
-            dy0 = __float2int_rn(b * (float)(1 << shift) / fabsf(a));
-            y0 = (y0 << shift) + (1 << (shift - 1));
-        } else {
-            xflag = 0;
-            dy0 = b > 0 ? 1 : -1;
-            dx0 = __float2int_rn(a * (float)(1 << shift) / fabsf(b));
-            x0 = (x0 << shift) + (1 << (shift - 1));
-        }
-        int ends[2][3];
-        for (int k = 0; k < 2; ++k) {
-            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
-            int gap = 0, et = 0;
-            bool done = false;
-            for (int t0 = 0; !done; t0 += 64) {
-                const int t = t0 + lane;
-                const int x = x0 + t * dx, y = y0 + t * dy;
-                int i1, j1;
-                if (xflag) j1 = x, i1 = y >> shift; else j1 = x >> shift, i1 = y;
-                const bool inb = j1 >= 0 && j1 < w && i1 >= 0 && i1 < h;
-                const bool on = inb && live(j1, i1);
-                const unsigned long long fo = __ballot(on), fi = __ballot(inb);
-                const int nin = fi == ~0ull ? 64 : __ffsll((long long)~fi) - 1;         // in-bounds steps of this word
-                int pos = 0;
-                if (cfg.line_gap >= 63 && nin > 0) {           // no run of zeros inside one word can exceed the gap
-                    const unsigned long long f = nin == 64 ? fo : fo & ((1ull << nin) - 1ull);
-                    if (f == 0ull) {
-                        if (gap + nin > cfg.line_gap) done = true;
-                        gap += nin;
-                    } else if (gap + (__ffsll((long long)f) - 1) > cfg.line_gap) {
-                        done = true;
-                    } else {
-                        const int last = 63 - __clzll((long long)f);
-                        et = t0 + last;
-                        gap = nin - 1 - last;
-                    }
-                    pos = nin;
-                }
-                while (pos < nin) {                                                        // the gap rule (line_gap >= 1)
-                    const unsigned long long rest = fo >> pos;
-                    int z = rest == 0ull ? 64 : __ffsll((long long)rest) - 1;            // zeros before the next hit
-                    if (z >= nin - pos) {
-                        const int zeros = nin - pos;
-                        if (gap + zeros > cfg.line_gap) done = true;
-                        gap += zeros;
-                        pos = nin;
-                        break;
-                    }
-                    if (gap + z > cfg.line_gap) { done = true; break; }
-                    pos += z;
-                    gap = 0;
-                    et = t0 + pos;
-                    ++pos;
-                }
-                if (nin < 64) done = true;                                                 // left the image
-            }
-            const int xx = x0 + et * dx, yy = y0 + et * dy;
-            ends[k][0] = xflag ? xx : xx >> shift, ends[k][1] = xflag ? yy >> shift : yy, ends[k][2] = et;
-        }
-        const int e0x = ends[0][0], e0y = ends[0][1], e1x = ends[1][0], e1y = ends[1][1];
-        const bool good = abs(e1x - e0x) >= cfg.line_length || abs(e1y - e0y) >= cfg.line_length;
-        if (lane == 0) {
-            sh_er[0] = x0, sh_er[1] = y0, sh_er[2] = dx0, sh_er[3] = dy0, sh_er[4] = xflag, sh_er[5] = good ? 1 : 0;
-            sh_er[6] = ends[0][2], sh_er[7] = ends[1][2];
-        }
-        command(CMD_ERASE);                        // the helper takes direction 1, this wave direction 0
-        erase_dir(0);
-        join();
-        if (good) {
-            if (g == 0 && lane == 0) {
-                int* o = segs + ((size_t)s * cfg.max_segments + nlines) * 4;
-                o[0] = e0x, o[1] = e0y, o[2] = e1x, o[3] = e1y;
-            }
-            if (++nlines >= cfg.max_segments) break;
-        }
+        if (wv == 0) erase_bitmap(0);              // this wave direction 0, the helper direction 1
+        else if (wv == HVW) erase_bitmap(1);
+        __syncthreads();                           // B6: the erased pixels' bits
+        const bool good = sh_er[5] != 0;
+        if (good && voter) erase_votes();          // (runs beside wave 0's next batch forming: the rows are this wave's own)
+        if (good && ++nlines >= cfg.max_segments) break;
     }
-    finish();
-    if (g == 0 && lane == 0) nseg[s] = nlines, path[s] = 1;
+    if (wv == 0 && g == 0 && lane == 0) nseg[s] = nlines, path[s] = 1;
 }
 
 // ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
@@ -3030,7 +3044,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
             const char* sp = getenv("AVHOT_HOUGH_SPIN");
             const char* dr = getenv("AVHOT_HOUGH_DROP");
             const int spin = sp && atoi(sp) > 0 ? atoi(sp) : HS_SPIN;
-            hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3(128), 0, st, h, w, L.numrho, hc, nz, npts, accum,
+            hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3((HVW + 1) * 64), 0, st, h, w, L.numrho, hc, nz, npts, accum,
                                lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath);
             AV_LAUNCH_CHECK();
         }
