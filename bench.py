@@ -385,12 +385,13 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                       "trajectories in another; %d of %d CUs, microseconds of dependent work each" % (min(2 * S, N_CUS), N_CUS),
                "cus_occupied": min(2 * S, N_CUS), "bytes_per_launch": (TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb,
                "achieved": hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused) / HBM_PEAK_GBS, 5), "traffic": None}]
+               "frac": round(hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused) / HBM_PEAK_GBS, 5),
+               "traffic": pmc_traffic("hot_step_pmc.json", "hbm_bytes_per_stream_step", F)}]
     dom = max(ks, key=lambda k: k["avg_ms"])
     roof = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch") if k in dom}
     roof["avg_launch_ms"] = round(dom["avg_ms"], 5)
     roof["traffic"] = dom.get("traffic")
-    if dom.get("traffic") is None and dom["kernel"] in ("tracker_kernel", "planner_wave_kernel"):
+    if dom.get("traffic") is None and dom["kernel"] in ("tracker_kernel", "planner_wave_kernel", "hot_step_kernel"):
         roof["traffic_stale"] = True         # the counter profile was measured on another version of the kernel's source
     if dom["bound"] == "latency":
         roof["cus_occupied"] = dom.get("cus_occupied")
@@ -422,7 +423,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         out["config"]["allgather_bytes_per_rank_per_step"] = xchg.bytes_per_step
     if stage_kernels is not None:
         out["stage_kernels_replaced"] = stage_kernels
-    out["traffic_profiles"] = [pmc_stamp("tracker_pmc.json"), pmc_stamp("planner_pmc.json")]
+    out["traffic_profiles"] = [pmc_stamp("hot_step_pmc.json")] if loop.fused_step else [pmc_stamp("tracker_pmc.json"), pmc_stamp("planner_pmc.json")]
     if W == 1:
         out["us_per_time_step"] = round(el / nsteps * 1e6, 3)
     del loop, xchg
@@ -504,7 +505,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6, precision
                     "decode in the head's last convolutions) + sppf + upsample + radix sort + NMS"), "stage": "detect", "branch": "main",
          "avg_ms": t_yolo, "bound": "mfma",
          "flops_per_launch": int(fl), "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s",
-         "frac": round(tf / mfma_peak, 4)},
+         "frac": round(tf / mfma_peak, 4),
+         "traffic": None if fp32 else pmc_traffic("yolo_hbm_pmc.json", "hbm_bytes_per_forward", S / 64.0)},
         {"kernel": "lane pixel stages: " + loop.lane_pixel_kernels, "stage": "lane (pixels)", "branch": "side",
          "avg_ms": t_pix, "bound": "hbm", "bytes_per_launch": pix_bytes,
          "achieved": round(pix_bytes / (t_pix * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -542,7 +544,7 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6, precision
                           "frac": round(lane_total / (lane_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": "SURVEY 8d: 7*W*H algorithmic bytes per frame over pixel stages + Hough + fit"},
            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
-    out["traffic_profiles"] = [pmc_stamp("lane_pmc.json"), pmc_stamp("yolo_mfma_pmc.json")]
+    out["traffic_profiles"] = [pmc_stamp("lane_pmc.json"), pmc_stamp("yolo_mfma_pmc.json"), pmc_stamp("yolo_hbm_pmc.json")]
     del loop
     torch.cuda.empty_cache()
     return out

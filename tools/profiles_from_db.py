@@ -62,7 +62,7 @@ def counters(name):
     return out
 
 
-for nm in ("bench_config4", "bench_config4_w1", "bench_config3", "bench_config2", "lane_S64", "yolo_b64"):
+for nm in ("bench_config4", "bench_config4_window256", "bench_config3", "bench_config2", "lane_S64", "yolo_b64", "yolo_b64_fp32", "yolo_b1_frame"):
     stats(nm, "%s_%s_kernel_stats.csv" % (tag, nm))
 
 # ---- YOLO: launch-by-launch timeline of the last forward of the trace (tools/ytimeline.py) ---------------------------------
@@ -82,9 +82,10 @@ lane = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_*
                   "64 frames of 1280x720 per launch; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)",
         "pixels_per_launch": px, "kernels": {}}
 pix_total = 0.0
-pixel_kernels = ("front_pack", "front_stream", "thresholds_kernel", "ccl_tile_kernel", "ccl_border_kernel", "finalize_fast", "compact_box_kernel")
+pixel_kernels = ("front_pack", "front_stream", "thresholds_kernel", "ccl_tile_kernel", "ccl_border_kernel", "finalize_fast", "resolve_bits_kernel",
+                 "compact_box_kernel")
 for k in sorted(set(fe) | set(wr)):
-    if not any(t in k for t in ("front_pack", "front_stream", "thresholds", "ccl_", "finalize", "compact", "hough", "lane_fit")):
+    if not any(t in k for t in ("front_pack", "front_stream", "thresholds", "ccl_", "finalize", "resolve_bits", "compact", "hough", "lane_fit")):
         continue
     f = 2.0 * fe.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0
     w_ = wr.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
@@ -130,6 +131,55 @@ for k in fe:
                    "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)", "hbm_bytes_per_launch": int(f + w_),
                    "hbm_bytes_per_frame": round((f + w_) / frames, 1), "algorithmic_bytes_per_frame": 4776, **stamp("tracker.hip")},
                   open(os.path.join(dst, "tracker_pmc.json"), "w"), indent=2)
+
+# ---- the one-launch time-step (headline): HBM bytes per launch ------------------------------------------------------------------
+fe, wr = counters("step_fetch"), counters("step_write")
+for k in fe:
+    if "hot_step_kernel" in k and k in wr:
+        f, w_ = 2.0 * fe[k]["FETCH_SIZE"] * 1024.0, wr[k]["WRITE_SIZE"] * 1024.0
+        json.dump({"kernel": k, "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, each with --kernel-trace only) -- "
+                                          "python3 bench.py --no-also --no-cpu-baseline (64 streams, one launch per time-step), MI355X, " + tag,
+                   "streams_per_launch": 64, "WRITE_SIZE_KiB": wr[k]["WRITE_SIZE"], "FETCH_SIZE_KiB_raw": fe[k]["FETCH_SIZE"],
+                   "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)", "hbm_bytes_per_launch": int(f + w_),
+                   "hbm_bytes_per_stream_step": round((f + w_) / 64.0, 1), "algorithmic_bytes_per_stream_step": 4776 + 768 + 228 + 51660,
+                   **stamp("step.hip")}, open(os.path.join(dst, "hot_step_pmc.json"), "w"), indent=2)
+
+# ---- YOLO: HBM bytes per kernel family and per forward (FETCH_SIZE x2 + WRITE_SIZE, separate passes) ----------------------------
+fe, wr = counters("yolo_fetch"), counters("yolo_write")
+if fe and wr:
+    fam, tot_f, tot_w = {}, 0.0, 0.0
+    # launches per forward: the profiled run does a fixed number of forwards (ybench: 1 warm-up + reps); normalise per forward by
+    # the launch count of a kernel that runs exactly once per forward
+    nfw = max(1, fe.get("front_fused_kernel", {}).get("launches", 1))
+    for k in sorted(set(fe) & set(wr)):
+        if not any(t in k for t in ("conv", "c2f", "front_fused", "sppf", "nms", "upsample", "preprocess", "decode", "maxpool")):
+            continue
+        n = fe[k]["launches"]
+        f, w_ = 2.0 * fe[k]["FETCH_SIZE"] * 1024.0 * n / nfw, wr[k]["WRITE_SIZE"] * 1024.0 * n / nfw
+        fam[k] = {"launches_per_forward": round(n / nfw, 2), "avg_us": round(fe[k]["avg_ns"] / 1e3, 2), "fetch_bytes_per_forward": int(f),
+                  "write_bytes_per_forward": int(w_), "hbm_GBs_while_running": round((f + w_) / max(fe[k]["avg_ns"] * n / nfw, 1.0), 1)}
+        tot_f += f
+        tot_w += w_
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/ybench.py --batch 64 --reps 2; "
+                         "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B); bytes per forward of 64 frames",
+               "hbm_bytes_per_forward": int(tot_f + tot_w), "fetch_bytes_per_forward": int(tot_f), "write_bytes_per_forward": int(tot_w),
+               "kernels": fam, **stamp("yolo.hip")}, open(os.path.join(dst, "yolo_hbm_pmc.json"), "w"), indent=1)
+
+# ---- YOLO: LDS bank conflicts / instruction mix per convolution family -------------------------------------------------------------
+ld = counters("yolo_lds")
+if ld:
+    per = {}
+    for k, q in ld.items():
+        if not any(t in k for t in ("conv", "c2f", "front_fused")):
+            continue
+        act, mf_ = q.get("SQ_LDS_IDX_ACTIVE", 0.0), q.get("SQ_INSTS_MFMA", 0.0)
+        per[k] = {"launches": q["launches"], "avg_us": round(q["avg_ns"] / 1e3, 2),
+                  "lds_conflict_cycles_over_lds_active": round(q.get("SQ_LDS_BANK_CONFLICT", 0.0) / act, 4) if act else None,
+                  "lds_insts_per_mfma": round(q.get("SQ_INSTS_LDS", 0.0) / mf_, 2) if mf_ else None,
+                  "valu_insts_per_mfma": round(q.get("SQ_INSTS_VALU", 0.0) / mf_, 2) if mf_ else None}
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVES -- "
+                         "python3 tools/ybench.py --batch 64 --reps 2 (MI355X, " + tag + ")", "kernels": per, **stamp("yolo.hip")},
+              open(os.path.join(dst, "yolo_lds_pmc.json"), "w"), indent=1)
 
 # ---- YOLO: MFMA busy ------------------------------------------------------------------------------------------------------------
 mf = counters("yolo_mfma")
