@@ -1829,18 +1829,14 @@ __device__ __forceinline__ bool nms_over(const float4 a, float aa, const float4 
     return inter / (aa + bb - inter) > thr;
 }
 
-// Greedy NMS over the sorted candidates, one workgroup of NMS_WAVES waves per image; identical decisions to box-at-a-time greedy
-// suppression (a box is dropped iff an earlier KEPT box overlaps it).  Round 4 form.  With random weights every one of the 5040
-// anchors passes the confidence filter and ~1700 sorted candidates have to be walked to keep 300; round 3 walked them 64 at a time
-// (27 chunks x 3.8 us).  Most of a chunk was dead on arrival -- suppressed by boxes kept long before -- and still cost a chunk.
-// Now a WINDOW of 1024 candidates is live at once, one per thread, in registers:
-//   * on entry every thread tests its candidate against everything kept so far;
-//   * a round takes the first 64 candidates of the window that are still alive (ranks from the waves' ballots), i.e. candidates
-//     that no box kept so far suppresses -- only their own round mates can -- lays their 64 x 64 suppression relation down in LDS
-//     (all sixteen waves: four pairs per thread, one atomic OR of a nibble), and wave 0 walks it in order with scalar bit
-//     arithmetic: a kept row clears its victims, a cleared member suppresses nobody;
-//   * every candidate behind the round is tested against the round's new boxes (at most 64) by its own thread.
-// A round costs about as much as a chunk did but disposes of 64 ALIVE candidates (tools / profiles: ~10 rounds instead of 27 chunks).
+// Greedy NMS over the sorted candidates, one workgroup of NMS_WAVES waves per image.  Candidates are taken 64
+// at a time (lane = candidate).  A chunk is tested against the boxes kept so far (kept box k belongs to one wave; boxes
+// broadcast from LDS; per-wave survivor masks AND-ed) and then resolves itself in order, in wave 0, with a ballot loop over its
+// still-alive members.  The two halves are PIPELINED: while wave 0 resolves chunk c, the other fifteen waves already test chunk
+// c + 1 against everything kept BEFORE chunk c; once chunk c's survivors are known, all sixteen test chunk c + 1 against just
+// those (at most 64 boxes, four per wave).  Identical decisions to box-at-a-time greedy suppression (a box is dropped iff an
+// earlier KEPT box overlaps it); per chunk the critical path is max(resolve, test) + a short increment instead of their sum
+// (5 us -> 3.5 us; with random weights ~27 chunks are walked to keep 300 boxes).
 constexpr int NMS_WAVES = 16;
 __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     int A, int max_det, float iou_thres, const float* __restrict__ sbox, const int* __restrict__ scount,
@@ -1851,91 +1847,67 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     float4* kbx = reinterpret_cast<float4*>(nms_smem);                      // kept boxes [max_det]
     float* kar = reinterpret_cast<float*>(kbx + max_det);                   // their areas
     int* kix = reinterpret_cast<int*>(kar + max_det);                       // their position in the sorted list
-    __shared__ unsigned long long wm[NMS_WAVES];                            // alive masks of the window, one word per wave
-    __shared__ float4 cbx[64];                                              // the round's members
-    __shared__ float car[64];
-    __shared__ int cix[64];
-    __shared__ unsigned rows[64][2];                                        // rows[a]: members a suppresses (bit b, b > a)
+    __shared__ unsigned long long m_old[NMS_WAVES], m_new[NMS_WAVES];       // survivor masks of the chunk wave 0 resolves next
     __shared__ int s_kept;
-    constexpr int WIN = 64 * NMS_WAVES;
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, cnt = scount[n];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, cnt = scount[n];
     const float4* sb = reinterpret_cast<const float4*>(sbox) + (size_t)n * A;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) m_old[wid] = ~0ull, m_new[wid] = ~0ull;                  // chunk 0: nothing kept yet
     int kept = 0;
-    float4 bnext = tid < cnt ? sb[tid] : zero4;
-    for (int win0 = 0; win0 < cnt && kept < max_det; win0 += WIN) {
-        const int i = win0 + tid;
-        const float4 b = bnext;
-        bnext = i + WIN < cnt ? sb[i + WIN] : zero4;                       // the next window's candidate: in flight during this one
-        const float bb = (b.z - b.x) * (b.w - b.y);
-        bool alive = i < cnt;
-        for (int k = 0; k < kept && alive; ++k)                             // (first window: nothing kept yet)
-            if (nms_over(kbx[k], kar[k], b, bb, iou_thres)) alive = false;
-        for (;;) {
-            // ---- the first 64 alive candidates of the window ------------------------------------------------------------------------
-            const unsigned long long mine = __ballot(alive);
-            if (lane == 0) wm[wid] = mine;
-            if (tid < 64) rows[tid][0] = 0u, rows[tid][1] = 0u;
-            __syncthreads();
-            int before = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < NMS_WAVES; ++w) {
-                const int c = __popcll(wm[w]);
-                before += w < wid ? c : 0;
-                tot += c;
-            }
-            if (tot == 0) break;                                            // window exhausted (uniform)
-            const int nch = tot < 64 ? tot : 64;
-            const int rank = before + __popcll(mine & ((1ull << lane) - 1ull));
-            const bool member = alive && rank < 64;
-            if (member) cbx[rank] = b, car[rank] = bb, cix[rank] = i;
-            __syncthreads();
-            // ---- who suppresses whom inside the round: thread = (member a = lane, members 4 wid .. 4 wid + 3) ------------------------
-            {
-                unsigned bits = 0;
-                if (lane < nch) {
-                    const float4 ba = cbx[lane];
-                    const float aa = car[lane];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int q = 4 * wid + c;
-                        if (q > lane && q < nch && nms_over(ba, aa, cbx[q], car[q], iou_thres)) bits |= 1u << c;
-                    }
-                }
-                if (bits) atomicOr(&rows[lane][(4 * wid) >> 5], bits << ((4 * wid) & 31));
-            }
-            __syncthreads();
-            // ---- wave 0: in order, a kept member clears its victims ---------------------------------------------------------------------
-            if (wid == 0) {
-                const unsigned r0 = rows[lane][0], r1 = rows[lane][1];
-                unsigned long long live = nch == 64 ? ~0ull : (1ull << nch) - 1ull, keepm = 0ull, todo = live;
-                while (todo) {
-                    const int a = __ffsll((long long)todo) - 1;
-                    keepm |= 1ull << a;
-                    const unsigned long long victims = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)r1, a) << 32) |
-                                                       (unsigned)__builtin_amdgcn_readlane((int)r0, a);
-                    live &= ~victims;
-                    todo = a == 63 ? 0ull : live & ~((2ull << a) - 1ull);
-                }
-                const int pos = kept + __popcll(keepm & ((1ull << lane) - 1ull));
-                if (((keepm >> lane) & 1ull) && pos < max_det) kbx[pos] = cbx[lane], kar[pos] = car[lane], kix[pos] = cix[lane];
-                int nk = kept + __popcll(keepm);
-                nk = nk > max_det ? max_det : nk;
-                if (lane == 0) s_kept = nk;
-            }
-            __syncthreads();
-            const int kept1 = s_kept;
-            if (member) alive = false;                                      // decided
-            // ---- everybody behind the round against the round's new boxes ------------------------------------------------------------
-            for (int k = kept; k < kept1 && alive; ++k)
-                if (nms_over(kbx[k], kar[k], b, bb, iou_thres)) alive = false;
-            kept = kept1;
-            if (kept >= max_det) break;                                     // (uniform)
-        }
-        __syncthreads();                                                    // (the break on tot == 0 leaves between two barriers of the loop)
-    }
+    float4 b = lane < cnt ? sb[lane] : zero4;                               // chunk c
+    float4 b1 = lane + 64 < cnt ? sb[lane + 64] : zero4;                    // chunk c + 1
     __syncthreads();
-    // the detections, all at once (the gathers through sidx would otherwise sit in the round loop's critical path)
+    for (int base = 0; base < cnt && kept < max_det; base += 64) {
+        const int i = base + lane;
+        const float bb = (b.z - b.x) * (b.w - b.y), bb1 = (b1.z - b1.x) * (b1.w - b1.y);
+        const float4 b2 = i + 128 < cnt ? sb[i + 128] : zero4;             // chunk c + 2: in flight during this iteration
+        unsigned long long early = ~0ull;
+        if (wid == 0) {
+            // ---- resolve chunk c -----------------------------------------------------------------------------------------------
+            unsigned long long m = __ballot(i < cnt);
+#pragma unroll
+            for (int w = 0; w < NMS_WAVES; ++w) m &= m_old[w] & m_new[w];
+            bool alive = (m >> lane) & 1ull;
+            unsigned long long todo = m;
+            while (todo) {
+                const int li = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                float4 a;
+                a.x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.x), li));
+                a.y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.y), li));
+                a.z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.z), li));
+                a.w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(b.w), li));
+                const float aa = (a.z - a.x) * (a.w - a.y);
+                if (lane > li && alive && nms_over(a, aa, b, bb, iou_thres)) alive = false;
+                m = __ballot(alive);
+                todo &= m;                       // a member suppressed just now no longer suppresses anyone
+            }
+            const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+            if (alive && pos < max_det) kbx[pos] = b, kar[pos] = bb, kix[pos] = i;
+            int nk = kept + __popcll(m);
+            nk = nk > max_det ? max_det : nk;
+            if (lane == 0) s_kept = nk;
+        } else {
+            // ---- meanwhile: chunk c + 1 against everything kept before chunk c (fifteen waves) -------------------------------------------
+            bool alive1 = true;
+            for (int k = wid - 1; k < kept; k += NMS_WAVES - 1)
+                if (nms_over(kbx[k], kar[k], b1, bb1, iou_thres)) alive1 = false;
+            early = __ballot(alive1);
+        }
+        __syncthreads();                         // chunk c's survivors are in kbx; wave 0 is done reading the masks
+        const int kept1 = s_kept;
+        {   // ---- chunk c + 1 against chunk c's survivors (all waves) ------------------------------------------------------------------
+            bool alive1 = true;
+            for (int k = kept + wid; k < kept1; k += NMS_WAVES)
+                if (nms_over(kbx[k], kar[k], b1, bb1, iou_thres)) alive1 = false;
+            const unsigned long long late = __ballot(alive1);
+            if (lane == 0) m_old[wid] = early, m_new[wid] = late;
+        }
+        __syncthreads();
+        kept = kept1;
+        b = b1, b1 = b2;
+    }
+    // the detections, all at once (the gathers through sidx would otherwise sit in the chunk loop's critical path)
     for (int pos = threadIdx.x; pos < kept; pos += 64 * NMS_WAVES) {
         const int an = sidx[(size_t)n * A + kix[pos]];
         const float* c = cbox + ((size_t)n * A + an) * 4;
@@ -1948,6 +1920,7 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     if (threadIdx.x == 0) det_n[n] = kept;
 }
 
+// ---- host side: graph of layers --------------------------------------------------------------------------------
 
 // ---- reference-precision mode (av_yolo_create_ex(..., AV_YOLO_FP32)) ------------------------------------------------------------
 // The reference runs ultralytics on torch float32 (detector.py:103-123).  The production path above takes IEEE-half operands; this
@@ -2094,8 +2067,6 @@ __global__ void upsample2_f32_kernel(const float* in, int cs_in, int coff_in, fl
     *reinterpret_cast<f32x4*>(out + (size_t)p * cs_out + coff_out + c4 * 4) =
         *reinterpret_cast<const f32x4*>(in + ((size_t)(n * H + (y >> 1)) * W + (x >> 1)) * cs_in + coff_in + c4 * 4);
 }
-
-// ---- host side: graph of layers --------------------------------------------------------------------------------
 
 struct Buf { half_t* p = nullptr; int C = 0, H = 0, W = 0; };     // (reference-precision mode: the same pointer holds float elements)
 struct Slice { int buf, coff, c; };
