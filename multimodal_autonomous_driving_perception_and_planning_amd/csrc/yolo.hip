@@ -1920,7 +1920,6 @@ __global__ void __launch_bounds__(64 * NMS_WAVES) nms_greedy_kernel(
     if (threadIdx.x == 0) det_n[n] = kept;
 }
 
-// ---- host side: graph of layers --------------------------------------------------------------------------------
 
 // ---- reference-precision mode (av_yolo_create_ex(..., AV_YOLO_FP32)) ------------------------------------------------------------
 // The reference runs ultralytics on torch float32 (detector.py:103-123).  The production path above takes IEEE-half operands; this
@@ -2067,6 +2066,8 @@ __global__ void upsample2_f32_kernel(const float* in, int cs_in, int coff_in, fl
     *reinterpret_cast<f32x4*>(out + (size_t)p * cs_out + coff_out + c4 * 4) =
         *reinterpret_cast<const f32x4*>(in + ((size_t)(n * H + (y >> 1)) * W + (x >> 1)) * cs_in + coff_in + c4 * 4);
 }
+
+// ---- host side: graph of layers --------------------------------------------------------------------------------
 
 struct Buf { half_t* p = nullptr; int C = 0, H = 0, W = 0; };     // (reference-precision mode: the same pointer holds float elements)
 struct Slice { int buf, coff, c; };
