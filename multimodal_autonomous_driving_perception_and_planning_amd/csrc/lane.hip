@@ -125,15 +125,26 @@ __global__ void __launch_bounds__(256) thresholds_kernel(int h, int w, unsigned*
     hist[(size_t)s * 256 + tid] = 0;                    // ready for the next frame
     for (int i = tid; i < h; i += 256) rowcnt[(size_t)s * h + i] = 0;
     __syncthreads();
-    if (tid == 0) {
-        const long long n = (long long)h * w, k1 = (n - 1) / 2, k2 = n / 2;
-        long long c = 0;
-        int v1 = -1, v2 = -1;
-        for (int v = 0; v < 256; ++v) {
-            c += hh[v];
-            if (v1 < 0 && c > k1) v1 = v;
-            if (v2 < 0 && c > k2) { v2 = v; break; }
+    // the two middle order statistics from the cumulative histogram: the first wave, four bins per lane, prefix over the lanes
+    // (one thread walking the 256 bins was ~2 us of this 8-us launch); h * w < 2^31 (av_lane_detect), so the counts fit 32 bits
+    if (tid < 64) {
+        const unsigned a0 = hh[4 * tid], a1 = hh[4 * tid + 1], a2 = hh[4 * tid + 2], a3 = hh[4 * tid + 3], loc = a0 + a1 + a2 + a3;
+        unsigned inc = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(inc, d, 64);
+            if (tid >= d) inc += t;
         }
+        const unsigned exc = inc - loc;
+        const unsigned n = (unsigned)((long long)h * w), k1 = (n - 1) / 2, k2 = n / 2;
+        auto bin_over = [&](unsigned k) -> int {          // first bin whose cumulative count exceeds k
+            const bool here = inc > k && exc <= k;
+            const int v = 4 * tid + (exc + a0 > k ? 0 : (exc + a0 + a1 > k ? 1 : (exc + a0 + a1 + a2 > k ? 2 : 3)));
+            const unsigned long long m = __ballot(here);
+            return __builtin_amdgcn_readlane(v, m ? __ffsll((long long)m) - 1 : 0);
+        };
+        const int v1 = bin_over(k1), v2 = bin_over(k2);
+        if (tid != 0) return;
         const double med = ((double)v1 + (double)v2) / 2.0;          // np.median, even count
         const double l = 0.7 * med, u = 1.3 * med;
         double* o = thr + (size_t)s * 4;
@@ -1191,15 +1202,29 @@ __global__ void __launch_bounds__(64, 5) front_pack(const uint8_t* __restrict__ 
 
 // candidate / strong bits of 16 map bytes.  NM: the fused front end's non-maximum-suppressed magnitudes against the
 // halved thresholds; otherwise the {0 weak, 1 none, 2 strong} codes of the two-pass kernels.
+// NM, four bytes at a time: byte > t for a threshold t <= 127 (the halved Canny thresholds) is bit 7 of ((b & 0x7F) + 0x7F - t) | b -- no
+// carry leaves a byte -- and a multiply gathers the four bits: 7 operations per word and threshold instead of ~5 per byte.
+__device__ __forceinline__ unsigned gt_nibble(unsigned x, unsigned x7, unsigned k) {      // x7 = x & 0x7F7F7F7F, k = (0x7F - t) * 0x01010101
+    const unsigned m = ((x7 + k) | x) & 0x80808080u;
+    return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;                                          // bits 0, 8, 16, 24 -> bits 21 .. 24 of the product
+}
 template <bool NM>
 __device__ __forceinline__ void map_bits(const uint4& v, int lo2, int hi2, unsigned& cand, unsigned& strong) {
+    if (NM) {
+        const unsigned kl = (unsigned)(0x7F - lo2) * 0x01010101u, kh = (unsigned)(0x7F - hi2) * 0x01010101u;
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        cand = 0, strong = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned x7 = w[q] & 0x7F7F7F7Fu;
+            cand |= gt_nibble(w[q], x7, kl) << (4 * q), strong |= gt_nibble(w[q], x7, kh) << (4 * q);
+        }
+        return;
+    }
     const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
     cand = 0, strong = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (NM) cand |= ((int)b[k] > lo2 ? 1u : 0u) << k, strong |= ((int)b[k] > hi2 ? 1u : 0u) << k;
-        else cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
-    }
+    for (int k = 0; k < 16; ++k) cand |= (b[k] != 1 ? 1u : 0u) << k, strong |= (b[k] == 2 ? 1u : 0u) << k;
 }
 template <bool NM>
 __device__ __forceinline__ bool map_cand(uint8_t v, int lo2) { return NM ? (int)v > lo2 : v != 1; }
@@ -1560,7 +1585,15 @@ constexpr int CB_ROWS = 8192;                   // rows the scan holds (the box 
 __global__ void __launch_bounds__(1024) compact_box_kernel(const uint8_t* __restrict__ masked, int h, int w,
                                                            const int* __restrict__ rowcnt, unsigned* __restrict__ nz,
                                                            int* __restrict__ npts, int bx0, int by0, int bcw, int bch,
-                                                           const unsigned* __restrict__ kbits_all, int pw) {
+                                                           const unsigned* __restrict__ kbits_all, int pw,
+                                                           int* __restrict__ prep_accum, size_t accum_stride, int prep_words,
+                                                           int* __restrict__ prep_fallback) {
+    // prep_accum (or null): what hough_prep_kernel does for the sharded Hough kernel that follows in the same call -- this frame's
+    // exchange words and fallback flag cleared here instead of by a launch of its own
+    if (prep_accum && blockIdx.y == 0) {
+        if ((int)threadIdx.x < prep_words) prep_accum[(size_t)blockIdx.x * accum_stride + threadIdx.x] = 0;
+        if (threadIdx.x == 0) prep_fallback[blockIdx.x] = 0;
+    }
     // kbits_all: the kept-edge bit map of the box (resolve_bits_kernel), pw words per row -- a lane per 32-pixel word; else the
     // masked byte map, a lane per 16-pixel chunk
     extern __shared__ int cb_base[];                        // [bch] exclusive prefix of the box rows' counts
@@ -2884,6 +2917,9 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
     unsigned* rbits = (unsigned*)(ws + L.rbits);
     unsigned* kbits = (unsigned*)(ws + L.kbits);
     bool bitpath = false;            // this call resolved the ROI through the bit maps (no masked byte map written)
+    bool prepped = false;            // the compaction pass cleared the sharded Hough kernel's exchange words and fallback flags
+    const char* shard_env = getenv("AVHOT_HOUGH_SHARD");
+    const bool use_shard = !(stages & 8) && !(shard_env && atoi(shard_env) == 0);      // AVHOT_HOUGH_SHARD=0 skips the sharded kernel
     const dim3 tiles((w + TW - 1) / TW, (h + TH - 1) / TH, n_streams);
     const bool fastp = (w % 16 == 0) && w >= 32 && (((size_t)bgr | (size_t)workspace) & 15) == 0 &&
                        (long long)h * (w >> 4) < (1ll << 24);             // chunk_xy's exact range
@@ -3012,11 +3048,16 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                                roi_rows, (stages & 1) ? edges : nullptr, masked, rowcnt);
         }
         AV_LAUNCH_CHECK();
+        // (the fallback flags overlay the first n_streams row counters of frame 0: cleared by this pass only when those lie above the
+        // box rows it reads, and only when the Hough stage follows in this call)
+        const bool prep_here = bitpath && use_shard && !(stages & 2) && n_streams <= cbox[1] && fastp && cbox_rows <= CB_ROWS;
         if (fastp && cbox_rows <= CB_ROWS)
             hipLaunchKernelGGL(compact_box_kernel, dim3(n_streams, 4), dim3(1024), (size_t)cbox_rows * sizeof(int), st, masked, h, w,
-                               rowcnt, nz, npts, cbox[0], cbox[1], cbox[2], cbox[3], bitpath ? kbits : nullptr, bb.pw);
+                               rowcnt, nz, npts, cbox[0], cbox[1], cbox[2], cbox[3], bitpath ? kbits : nullptr, bb.pw,
+                               prep_here ? accum : nullptr, (size_t)NUMANGLE * L.numrho, 8 * HG, rowcnt);
         else hipLaunchKernelGGL(compact_kernel, dim3(h, n_streams), dim3(256), 0, st, masked, h, w, rowcnt, nz, npts);
         AV_LAUNCH_CHECK();
+        prepped = prep_here;
     }
     if (stages & 2) return AV_OK;                                  // pixel stages only (tests, profiling)
     HoughCfg hc{cfg->hough_threshold, cfg->min_line_length, cfg->max_line_gap, cfg->max_segments};
@@ -3036,11 +3077,11 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
         // theta-sharded LDS variant first (4 workgroups per frame); frames it cannot hold, or where a partner did not
         // show up in time, are flagged for houghp_fast, and what that cannot hold for houghp_kernel.
         // AVHOT_HOUGH_SHARD=0 skips the first stage.
-        const char* e = getenv("AVHOT_HOUGH_SHARD");
-        const bool use_shard = !(e && atoi(e) == 0);
         if (use_shard) {
-            hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 8 * HG + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
-            AV_LAUNCH_CHECK();
+            if (!prepped) {
+                hipLaunchKernelGGL(hough_prep_kernel, dim3((n_streams * 8 * HG + 255) / 256), dim3(256), 0, st, n_streams, L.numrho, accum, fb);
+                AV_LAUNCH_CHECK();
+            }
             const char* sp = getenv("AVHOT_HOUGH_SPIN");
             const char* dr = getenv("AVHOT_HOUGH_DROP");
             const int spin = sp && atoi(sp) > 0 ? atoi(sp) : HS_SPIN;
