@@ -2257,12 +2257,12 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     __shared__ unsigned nz[HS_NZ];
     __shared__ unsigned bm[HS_BMW];
     __shared__ int fifo[FIFO];
-    __shared__ int bpt2[2][HB];                  // batch points, double-buffered: the next batch is formed while the exchange is in flight
-    __shared__ float bfx2[2][HB], bfy2[2][HB];
+    __shared__ int bpt[HB];
+    __shared__ float bfx[HB], bfy[HB];
     __shared__ int row_sz[HQ * HTL];
     __shared__ unsigned long long ebits[2][HS_EB];             // live pixels found (and cleared) by the two directions of an erase
     __shared__ unsigned sh_hit[HVW], sh_key[HVW];
-    __shared__ int sh_nb, sh_head, sh_tail, sh_count, sh_big, sh_hits, sh_fail, sh_er[8], sh_formed;
+    __shared__ int sh_nb, sh_head, sh_tail, sh_count, sh_big, sh_hits, sh_fail, sh_er[8];
     const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);       // 0 .. HVW-1: voting waves (0 also runs the sequential part); HVW: helper
     const bool voter = wv < HVW;
@@ -2380,15 +2380,11 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     // one 64-bit word per workgroup, round and sequence parity: (sequence << 32) | payload, agent scope.  Wave 0 only; lane k < HG
     // polls partner k; the payloads are combined by the caller (OR of hit masks / maximum of keys)
     unsigned seq = 0;
-    auto post = [&](int round, unsigned payload) {
-        unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
-        const unsigned long long wd = ((unsigned long long)seq << 32) | payload;
-        const bool dropped = s == drop_frame && g == HG - 1 && seq == 1u && round == 0;
-        if (lane == 0 && !dropped) __hip_atomic_store(slot + g, wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto await = [&](int round, unsigned payload, unsigned& of_partner) -> bool {
+    auto exchange = [&](int round, unsigned payload, unsigned& of_partner) -> bool {
         unsigned long long* slot = xw + (size_t)(round * 2 + (seq & 1)) * HG;
         unsigned long long wd = ((unsigned long long)seq << 32) | payload;
+        const bool dropped = s == drop_frame && g == HG - 1 && seq == 1u && round == 0;
+        if (lane == 0 && !dropped) __hip_atomic_store(slot + g, wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true;
         if (lane < HG && lane != g) {
             int it = 0;
@@ -2486,50 +2482,41 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             }
         }
     };
-    // pops up to HB points that are still live from the FIFO into batch buffer `bufi`, starting at FIFO position `head` (advanced;
-    // not published: the caller decides whether the batch stands).  Wave 0 only.
-    // spec: forming ahead of the exchange's verdict -- nothing shared may change, so a FIFO that runs dry ends the attempt (-1).
-    auto form_batch = [&](int bufi, int& head, bool spec) -> int {
-        int nb = 0;
-        for (;;) {
-            const int avail = sh_tail - head;
-            if (avail == 0) {
-                if (sh_count == 0) break;
-                if (spec) return -1;
-                if (lane == 0) sh_head = head;
-                lds_order();
-                top_up(false);                 // (rare: the FIFO ran dry inside a batch -- the helper is idle whenever this wave forms)
-                continue;
-            }
-            const int take = avail < (HB - nb) ? avail : (HB - nb);
-            int p = 0;
-            bool ok = false;
-            if (lane < take) {
-                p = fifo[(head + lane) & (FIFO - 1)];
-                ok = live(p & 0xffff, p >> 16);
-            }
-            const unsigned long long okb = __ballot(ok);
-            if (ok) {
-                const int slot = nb + __popcll(okb & ((1ull << lane) - 1ull));
-                bpt2[bufi][slot] = p, bfx2[bufi][slot] = (float)(p & 0xffff), bfy2[bufi][slot] = (float)(p >> 16);
-            }
-            nb += __popcll(okb);
-            head += take;
-            if (nb == HB) break;
-        }
-        return nb;
-    };
-    int nlines = 0, cur = 0;                        // cur: batch buffer of this iteration (uniform: flips when a pre-formed batch is taken)
-    if (threadIdx.x == 0) sh_formed = 0;
+    int nlines = 0;
     if (wv == HVW) top_up(true);
     __syncthreads();
     // Phases of one batch; every wave passes the same barriers (B1 .. B6), all tests between them are workgroup-uniform (LDS words).
     for (;;) {
-        // ---- wave 0: form the batch (unless the previous iteration already did, below) ----------------------------------------------
-        if (wv == 0 && !sh_formed) {
+        // ---- wave 0: form the batch: pop up to HB points that are still live ------------------------------------------------------
+        if (wv == 0) {
             int head = sh_head;
-            const int nb0 = form_batch(cur, head, false);
-            if (lane == 0) sh_head = head, sh_nb = nb0;
+            int nb = 0;
+            for (;;) {
+                const int avail = sh_tail - head;
+                if (avail == 0) {
+                    if (sh_count == 0) break;
+                    if (lane == 0) sh_head = head;
+                    lds_order();
+                    top_up(false);                 // (rare: the FIFO ran dry inside a batch -- the helper is idle in this phase)
+                    continue;
+                }
+                const int take = avail < (HB - nb) ? avail : (HB - nb);
+                int p = 0;
+                bool ok = false;
+                if (lane < take) {
+                    p = fifo[(head + lane) & (FIFO - 1)];
+                    ok = live(p & 0xffff, p >> 16);
+                }
+                const unsigned long long okb = __ballot(ok);
+                if (ok) {
+                    const int slot = nb + __popcll(okb & ((1ull << lane) - 1ull));
+                    bpt[slot] = p, bfx[slot] = (float)(p & 0xffff), bfy[slot] = (float)(p >> 16);
+                }
+                nb += __popcll(okb);
+                head += take;
+                if (nb == HB) break;
+            }
+            if (lane == 0) sh_head = head, sh_nb = nb;
         }
         __syncthreads();                           // B1: the batch is in LDS
         const int nb = sh_nb;
@@ -2542,7 +2529,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             for (int v = 0; v < HNV; ++v) {
                 const int b = v * HNS + sub;
                 const bool bon = th_on && b < nb;
-                cel[v] = bon ? cellf(bfx2[cur][b < HB ? b : 0], bfy2[cur][b < HB ? b : 0]) : 0;
+                cel[v] = bon ? cellf(bfx[b < HB ? b : 0], bfy[b < HB ? b : 0]) : 0;
             }
 #pragma unroll
             for (int v = 0; v < HNV; ++v) {
@@ -2562,21 +2549,10 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
 #pragma unroll
             for (int v = 0; v < HVW; ++v) hitbits |= sh_hit[v];
             seq += 1;
-            post(0, hitbits);
-            // While the partners' words are on their way (~1 us through memory): the NEXT batch, formed as if this one fired no line
-            // (three batches in four).  It stands only if the frame's hit mask turns out empty -- then nothing was erased or pushed
-            // back and this is exactly the batch the next iteration would form; otherwise it is dropped (the FIFO position is
-            // published only when it stands).
-            int head2 = sh_head;
-            const int nb2 = form_batch(cur ^ 1, head2, true);
             unsigned got = 0;
-            const bool ok = await(0, hitbits, got);
+            const bool ok = exchange(0, hitbits, got);
             const unsigned hits = wave_or_u32(got);
-            const bool stands = ok && hits == 0u && nb2 >= 0;
-            if (lane == 0) {
-                sh_hits = (int)hits, sh_fail = ok ? 0 : 1, sh_formed = stands ? 1 : 0;
-                if (stands) sh_head = head2, sh_nb = nb2;
-            }
+            if (lane == 0) sh_hits = (int)hits, sh_fail = ok ? 0 : 1;
         }
         __syncthreads();                           // B3: the frame's hit mask
         if (sh_fail) {
@@ -2584,10 +2560,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             return;
         }
         const unsigned hits = (unsigned)sh_hits;
-        if (hits == 0) {
-            cur ^= 1;                              // the pre-formed batch is the next one
-            continue;
-        }
+        if (hits == 0) continue;
         const int bs = __ffs((int)hits) - 1;
         if (voter) {
             const int bsv = bs / HNS, bss = bs - bsv * HNS;
@@ -2612,18 +2585,17 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
 #pragma unroll
             for (int v = 0; v < HVW; ++v) lbest = sh_key[v] > lbest ? sh_key[v] : lbest;
             unsigned got = 0;
-            post(1, lbest);
-            const bool ok = await(1, lbest, got);
+            const bool ok = exchange(1, lbest, got);
             unsigned best = wave_max_u32(got);
             best ^= 0x80000000u;
             if (lane == 0) {
                 int head = sh_head;
-                for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt2[cur][b];
+                for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
                 sh_head = head;
             }
             lds_order();
             const int max_n = 255 - (int)(best & 255u);
-            const int j = bpt2[cur][bs] & 0xffff, i = bpt2[cur][bs] >> 16;
+            const int j = bpt[bs] & 0xffff, i = bpt[bs] >> 16;
             // ---- walk along the line in both directions ----------------------------------------------------------
             const float a = -trig[2 * max_n + 1], b = trig[2 * max_n];
             int x0 = j, y0 = i, dx0, dy0, xflag;
