@@ -2250,9 +2250,11 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
                                                    int* __restrict__ nseg, int* __restrict__ fallback, int spin_limit,
-                                                   int drop_frame, int* __restrict__ path) {
+                                                   int drop_frame, int* __restrict__ path, int timed) {
     // spin_limit: iterations an exchange waits for a partner before the frame is handed to houghp_fast; drop_frame (tests only,
-    // AVHOT_HOUGH_DROP): workgroup HG-1 of that frame never publishes its first exchange word, so its partners run into the limit
+    // AVHOT_HOUGH_DROP): workgroup HG-1 of that frame never publishes its first exchange word, so its partners run into the limit;
+    // timed (AVHOT_HOUGH_TIMED, tools/htime.py): wave 0 of workgroup 0 adds up s_memtime cycles per phase and leaves them behind
+    // the frame's exchange words (accumulator view, 64-bit words 32 .. 47)
     __shared__ unsigned acc_all[HVW][HS_ACCW];
     __shared__ unsigned nz[HS_NZ];
     __shared__ unsigned bm[HS_BMW];
@@ -2278,6 +2280,13 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     };
     constexpr int NTH = (HVW + 1) * 64;
+    unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = timed ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](int k) {                        // cycles since the previous lap -> phase k
+        if (timed) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            tph[k] += t - tlast, tlast = t;
+        }
+    };
     // the LDS clears do not depend on the point list: they run while its loads are in flight
     for (int i = (int)threadIdx.x; i < HVW * HS_ACCW; i += NTH) (&acc_all[0][0])[i] = HS_BIAS | (HS_BIAS << 16);
     for (int i = (int)threadIdx.x; i < HS_BMW; i += NTH) bm[i] = 0;
@@ -2485,6 +2494,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     int nlines = 0;
     if (wv == HVW) top_up(true);
     __syncthreads();
+    lap(0);                                        // set-up
     // Phases of one batch; every wave passes the same barriers (B1 .. B6), all tests between them are workgroup-uniform (LDS words).
     for (;;) {
         // ---- wave 0: form the batch: pop up to HB points that are still live ------------------------------------------------------
@@ -2518,6 +2528,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             }
             if (lane == 0) sh_head = head, sh_nb = nb;
         }
+        lap(1);                                    // batch forming
         __syncthreads();                           // B1: the batch is in LDS
         const int nb = sh_nb;
         if (nb == 0) break;
@@ -2544,6 +2555,8 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             top_up(true);
         }
         __syncthreads();                           // B2: hit masks of the four voting waves, FIFO refilled
+        lap(2);                                    // votes (and the helper's top-up) incl. both barriers
+        tph[10] += 1;
         if (wv == 0) {
             unsigned hitbits = 0;
 #pragma unroll
@@ -2555,6 +2568,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             if (lane == 0) sh_hits = (int)hits, sh_fail = ok ? 0 : 1;
         }
         __syncthreads();                           // B3: the frame's hit mask
+        lap(3);                                    // first exchange
         if (sh_fail) {
             give_up();
             return;
@@ -2580,6 +2594,8 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             }
         }
         __syncthreads();                           // B4: the workgroup's best keys
+        lap(4);                                    // keys, withdrawn votes
+        tph[11] += 1;
         if (wv == 0) {
             unsigned lbest = 0;
 #pragma unroll
@@ -2588,6 +2604,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             const bool ok = exchange(1, lbest, got);
             unsigned best = wave_max_u32(got);
             best ^= 0x80000000u;
+            lap(5);                                // second exchange
             if (lane == 0) {
                 int head = sh_head;
                 for (int b = nb - 1; b > bs; --b) fifo[(--head) & (FIFO - 1)] = bpt[b];
@@ -2674,6 +2691,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
             }
         }
         __syncthreads();                           // B5: the line
+        lap(6);                                    // line walk
         if (sh_fail) {
             give_up();
             return;
@@ -2681,11 +2699,15 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
         if (wv == 0) erase_bitmap(0);              // this wave direction 0, the helper direction 1
         else if (wv == HVW) erase_bitmap(1);
         __syncthreads();                           // B6: the erased pixels' bits
+        lap(7);                                    // erase, bitmap part
         const bool good = sh_er[5] != 0;
         if (good && voter) erase_votes();          // (runs beside wave 0's next batch forming: the rows are this wave's own)
+        lap(8);                                    // erase, accumulator part
         if (good && ++nlines >= cfg.max_segments) break;
     }
     if (wv == 0 && g == 0 && lane == 0) nseg[s] = nlines, path[s] = 1;
+    if (timed && wv == 0 && g == 0 && lane == 0)
+        for (int k = 0; k < 12; ++k) xw[32 + k] = tph[k];
 }
 
 // ---- L5-L7: slope split, quadratic fit, EMA, resampling ------------------------------------------------------
@@ -3086,7 +3108,7 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
             const char* dr = getenv("AVHOT_HOUGH_DROP");
             const int spin = sp && atoi(sp) > 0 ? atoi(sp) : HS_SPIN;
             hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3((HVW + 1) * 64), 0, st, h, w, L.numrho, hc, nz, npts, accum,
-                               lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath);
+                               lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath, getenv("AVHOT_HOUGH_TIMED") ? 1 : 0);
             AV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where the sharded PPHT kernel's time goes: AVHOT_HOUGH_TIMED=1 makes wave 0 of every frame's first workgroup add up s_memtime
+cycles (100 MHz constant clock on gfx950: 10 ns units) per phase; this prints them per frame and for the slowest frame."""
+import ctypes as C, os, sys
+os.environ["AVHOT_HOUGH_TIMED"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+from multimodal_autonomous_driving_perception_and_planning_amd.harness import synthetic_frame
+
+S, h, w, MS = 64, 720, 1280, 512
+ctx = nat.Context(0); L = nat.lib(); dev = torch.device("cuda", 0)
+frames = torch.as_tensor(np.stack([synthetic_frame(h, w, s % 8, 0) for s in range(S)])).to(dev)
+ws = torch.empty(int(L.av_lane_workspace_bytes(S, h, w, MS)), dtype=torch.uint8, device=dev)
+st = torch.cuda.Stream(); sh = C.c_void_p(st.cuda_stream)
+nat.check(L.av_lane_workspace_init(ctx.handle, sh, S, h, w, MS, nat.ptr(ws)))
+state = torch.zeros(S, 8, dtype=torch.float64, device=dev); poly = torch.zeros(S, 2, 3, dtype=torch.float64, device=dev)
+pts = torch.zeros(S, 2, 50, 2, dtype=torch.int32, device=dev); info = torch.zeros(S, 8, dtype=torch.int32, device=dev)
+conf = torch.zeros(S, 2, dtype=torch.float64, device=dev)
+cfg = nat.LaneCfg(50, 50, 150, MS, 0.7)
+for _ in range(3):
+    nat.check(L.av_lane_detect(ctx.handle, sh, C.byref(cfg), S, h, w, nat.ptr(frames), None, nat.ptr(ws), nat.ptr(state),
+                               nat.ptr(poly), nat.ptr(pts), nat.ptr(info), nat.ptr(conf), 0))
+st.synchronize()
+off, nb = C.c_size_t(), C.c_size_t()
+nat.check(L.av_lane_workspace_view(7, S, h, w, MS, C.byref(off), C.byref(nb)))
+per = nb.value // S
+names = ["setup", "form", "votes+topup", "exchange0", "keys+unvote", "exchange1", "walk", "erase bitmap", "erase votes", "-", "batches", "lines"]
+rows = []
+for s in range(S):
+    t = ws[off.value + s * per + 32 * 8: off.value + s * per + 44 * 8].cpu().numpy().view(np.uint64).astype(np.float64)
+    rows.append(t)
+rows = np.array(rows)
+tot = rows[:, :9].sum(axis=1)
+k = int(np.argmax(tot))
+print("s_memtime units of 10 ns; 64 frames (8 distinct), slowest frame %d: %.1f us, mean frame %.1f us" % (k, tot[k] / 100, tot.mean() / 100))
+for i, nme in enumerate(names):
+    if nme == "-":
+        continue
+    if i < 9:
+        print("  %-13s slowest %7.1f us (%4.1f %%)   mean %7.1f us" % (nme, rows[k, i] / 100, 100 * rows[k, i] / tot[k], rows[:, i].mean() / 100))
+    else:
+        print("  %-13s slowest %7d              mean %7.1f" % (nme, rows[k, i], rows[:, i].mean()))
