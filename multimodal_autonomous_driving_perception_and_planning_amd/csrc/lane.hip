@@ -2250,7 +2250,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
                                                    const int* __restrict__ npts, int* __restrict__ accum_all,
                                                    const float* __restrict__ trig, int* __restrict__ segs,
                                                    int* __restrict__ nseg, int* __restrict__ fallback, int spin_limit,
-                                                   int drop_frame, int* __restrict__ path, int timed) {
+                                                   int drop_frame, int* __restrict__ path, int timed, int xcd_local) {
     // spin_limit: iterations an exchange waits for a partner before the frame is handed to houghp_fast; drop_frame (tests only,
     // AVHOT_HOUGH_DROP): workgroup HG-1 of that frame never publishes its first exchange word, so its partners run into the limit;
     // timed (AVHOT_HOUGH_TIMED, tools/htime.py): wave 0 of workgroup 0 adds up s_memtime cycles per phase and leaves them behind
@@ -2265,7 +2265,14 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     __shared__ unsigned long long ebits[2][HS_EB];             // live pixels found (and cleared) by the two directions of an erase
     __shared__ unsigned sh_hit[HVW], sh_key[HVW];
     __shared__ int sh_nb, sh_head, sh_tail, sh_count, sh_big, sh_hits, sh_fail, sh_er[8];
-    const int s = blockIdx.x / HG, g = blockIdx.x % HG, lane = threadIdx.x & 63;
+    // Workgroups go round-robin over the 8 XCDs (blockIdx % 8): the four workgroups of a frame are given the same blockIdx % 8, so that
+    // their exchange words meet in one XCD's L2 (AVHOT_HOUGH_XCD=0: consecutive workgroups per frame).  Placement only: any map is correct.
+    int s = blockIdx.x / HG, g = blockIdx.x % HG;
+    if (xcd_local && (gridDim.x % (8 * HG)) == 0) {
+        const int b = blockIdx.x, blk = b / (8 * HG), r = b - blk * (8 * HG);
+        s = blk * 8 + (r & 7), g = r >> 3;
+    }
+    const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);       // 0 .. HVW-1: voting waves (0 also runs the sequential part); HVW: helper
     const bool voter = wv < HVW;
     const unsigned* nzg = nz_all + (size_t)s * h * w;
@@ -3108,7 +3115,8 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
             const char* dr = getenv("AVHOT_HOUGH_DROP");
             const int spin = sp && atoi(sp) > 0 ? atoi(sp) : HS_SPIN;
             hipLaunchKernelGGL(houghp_shard, dim3(n_streams * HG), dim3((HVW + 1) * 64), 0, st, h, w, L.numrho, hc, nz, npts, accum,
-                               lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath, getenv("AVHOT_HOUGH_TIMED") ? 1 : 0);
+                               lc->d_trig, segs, nseg, fb, spin, dr ? atoi(dr) : -1, hpath, getenv("AVHOT_HOUGH_TIMED") ? 1 : 0,
+                               (getenv("AVHOT_HOUGH_XCD") && atoi(getenv("AVHOT_HOUGH_XCD")) == 0) ? 0 : 1);
             AV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
