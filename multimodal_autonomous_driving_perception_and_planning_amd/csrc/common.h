@@ -30,6 +30,13 @@ struct av_ctx {
 
 void av_set_error(const char* fmt, ...);
 
+// Side streams come from a process-wide pool and go back to it (ctx.hip): they are never destroyed.  A context or detector handle
+// that is closed and a later one that is opened then leave the process with the SAME set of hardware queues -- destroying a used
+// stream and creating another changed how the streams of a later PerceptionLoop were served (bench config 3: 1.55 -> 2.9 ms per
+// step after any HotLoop had been deleted in the process; tools/c3seq.py).
+hipStream_t av_pool_stream_get(int device);      // nullptr on failure (error text set)
+void av_pool_stream_put(int device, hipStream_t s);
+
 #define AV_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

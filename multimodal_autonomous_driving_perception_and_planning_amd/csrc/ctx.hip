@@ -1,4 +1,5 @@
 // Context, error reporting, fork/join, hipGraph capture and event helpers of libavhot.so.
+#include <mutex>
 #include "common.h"
 
 #include <chrono>
@@ -14,6 +15,40 @@ void av_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+std::mutex g_pool_mu;
+std::vector<hipStream_t> g_stream_pool[64];
+}  // namespace
+
+hipStream_t av_pool_stream_get(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (device >= 0 && device < 64 && !g_stream_pool[device].empty()) {
+            hipStream_t s = g_stream_pool[device].back();
+            g_stream_pool[device].pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        av_set_error("hipStreamCreateWithFlags -> %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return s;
+}
+
+void av_pool_stream_put(int device, hipStream_t s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    if (device < 0 || device >= 64) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_stream_pool[device].push_back(s);
 }
 
 extern "C" {
@@ -53,7 +88,8 @@ int av_ctx_create(int device, av_ctx** out) {
     av_ctx* c = new (std::nothrow) av_ctx();
     AV_REQUIRE(c, AV_ENOMEM, "av_ctx_create: out of host memory");
     c->device = device;
-    AV_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    c->side = av_pool_stream_get(device);
+    AV_REQUIRE(c->side, AV_EHIP, "av_ctx_create: no side stream");
     AV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     AV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     // class cdf of the simulated detector (detector.py:159; legacy RandomState.choice: cumsum, /= last)
@@ -91,7 +127,7 @@ int av_ctx_destroy(av_ctx* ctx) {
     if (ctx->d_simtab) (void)hipFree(ctx->d_simtab);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    av_pool_stream_put(ctx->device, ctx->side);
     delete ctx;
     return AV_OK;
 }
