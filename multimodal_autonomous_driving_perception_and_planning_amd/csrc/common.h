@@ -36,11 +36,11 @@ void av_set_error(const char* fmt, ...);
 // the detector's main chain; which queues they got used to depend on how many streams the process had created and destroyed before
 // (1.55 ms per step in a fresh process, 2.9 ms after any HotLoop had been closed: the head's class branch and the tail of the previous
 // forward then shared a queue -- tools/c3seq.py, queue ids in a rocprofv3 kernel trace).  So: the pool creates its `normal` streams
-// four at a time, back to back (four consecutive creations = four different queues), hands them out oldest first and takes them back;
-// the Python loops enqueue their main chains on highest-priority streams (a queue class of their own).  (The deferred tail on a
-// LOWEST-priority stream was tried: 2.8-3.2 ms per step -- the next forward's head waits for it, and it starves.)
-hipStream_t av_pool_stream_get(int device);      // nullptr on failure (error text set)
-void av_pool_stream_put(int device, hipStream_t s);
+// four at a time, back to back (four consecutive creations = four different queues), hands them out and takes them back; streams that
+// are off every critical path (the detector's deferred tail) come from a second pool of LOWEST-priority streams, a queue class of
+// their own; the Python loops enqueue their main chains on highest-priority streams (a third class).
+hipStream_t av_pool_stream_get(int device, bool low_priority = false);      // nullptr on failure (error text set)
+void av_pool_stream_put(int device, hipStream_t s, bool low_priority = false);
 
 #define AV_HIP(expr)                                                                          \
     do {                                                                                      \

@@ -19,22 +19,26 @@ void av_set_error(const char* fmt, ...) {
 
 namespace {
 std::mutex g_pool_mu;
-std::vector<hipStream_t> g_stream_pool[64];
+std::vector<hipStream_t> g_stream_pool[64][2];      // [device][0 normal, 1 lowest priority]
 }  // namespace
 
-hipStream_t av_pool_stream_get(int device) {
+hipStream_t av_pool_stream_get(int device, bool low_priority) {
     if (device < 0 || device >= 64) {
         av_set_error("av_pool_stream_get: device %d", device);
         return nullptr;
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    std::vector<hipStream_t>& pool = g_stream_pool[device];
+    std::vector<hipStream_t>& pool = g_stream_pool[device][low_priority ? 1 : 0];
     if (pool.empty()) {
-        for (int i = 0; i < 4; ++i) {                  // a batch: consecutive creations land on different hardware queues
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int n = low_priority ? 2 : 4;            // a batch: consecutive creations land on different hardware queues
+        for (int i = 0; i < n; ++i) {
             hipStream_t s = nullptr;
-            const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            const hipError_t e = low_priority ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least)
+                                              : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
             if (e != hipSuccess) {
-                av_set_error("hipStreamCreateWithFlags -> %s", hipGetErrorString(e));
+                av_set_error("hipStreamCreate -> %s", hipGetErrorString(e));
                 break;
             }
             pool.insert(pool.begin(), s);             // (handed out in creation order: back() is the oldest)
@@ -46,12 +50,12 @@ hipStream_t av_pool_stream_get(int device) {
     return s;
 }
 
-void av_pool_stream_put(int device, hipStream_t s) {
+void av_pool_stream_put(int device, hipStream_t s, bool low_priority) {
     if (!s) return;
     (void)hipStreamSynchronize(s);
     if (device < 0 || device >= 64) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_stream_pool[device].push_back(s);
+    g_stream_pool[device][low_priority ? 1 : 0].push_back(s);
 }
 
 extern "C" {

@@ -2487,7 +2487,7 @@ int av_yolo_destroy(av_yolo* h) {
     if (!h) return AV_OK;
     for (void* p : h->y.allocs) (void)hipFree(p);
     av_pool_stream_put(h->y.ctx ? h->y.ctx->device : -1, h->y.side);      // (streams go back to the process-wide pool, common.h)
-    av_pool_stream_put(h->y.ctx ? h->y.ctx->device : -1, h->y.tail);
+    av_pool_stream_put(h->y.ctx ? h->y.ctx->device : -1, h->y.tail, true);
     if (h->y.ev_heads) (void)hipEventDestroy(h->y.ev_heads);
     if (h->y.ev_decoded) (void)hipEventDestroy(h->y.ev_decoded);
     if (h->y.ev_tail) (void)hipEventDestroy(h->y.ev_tail);
@@ -2946,7 +2946,7 @@ int av_yolo_defer_tail(av_yolo* h, int enable) {
     AV_REQUIRE(h, AV_EINVAL, "av_yolo_defer_tail: null handle");
     Yolo& y = h->y;
     if (enable && !y.tail) {
-        y.tail = av_pool_stream_get(y.ctx->device);
+        y.tail = av_pool_stream_get(y.ctx->device, true);      // off the critical path: a lowest-priority stream (own queue class)
         AV_REQUIRE(y.tail, AV_EHIP, "av_yolo_defer_tail: no stream");
         AV_HIP(hipEventCreateWithFlags(&y.ev_heads, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&y.ev_decoded, hipEventDisableTiming));
