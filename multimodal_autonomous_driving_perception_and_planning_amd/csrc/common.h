@@ -30,18 +30,6 @@ struct av_ctx {
 
 void av_set_error(const char* fmt, ...);
 
-// Side streams come from a process-wide pool (ctx.hip) and go back to it; they are never destroyed.  The HIP runtime serves a process's
-// streams from a few hardware queues (four per priority class by default), handed out in creation order, and two streams that share a
-// queue run one after the other.  bench config 3 needs the lane chain, the Detect head's class branch and the deferred tail to run BESIDE
-// the detector's main chain; which queues they got used to depend on how many streams the process had created and destroyed before
-// (1.55 ms per step in a fresh process, 2.9 ms after any HotLoop had been closed: the head's class branch and the tail of the previous
-// forward then shared a queue -- tools/c3seq.py, queue ids in a rocprofv3 kernel trace).  So: the pool creates its `normal` streams
-// four at a time, back to back (four consecutive creations = four different queues), hands them out and takes them back; streams that
-// are off every critical path (the detector's deferred tail) come from a second pool of LOWEST-priority streams, a queue class of
-// their own; the Python loops enqueue their main chains on highest-priority streams (a third class).
-hipStream_t av_pool_stream_get(int device, bool low_priority = false);      // nullptr on failure (error text set)
-void av_pool_stream_put(int device, hipStream_t s, bool low_priority = false);
-
 #define AV_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

@@ -1,5 +1,4 @@
 // Context, error reporting, fork/join, hipGraph capture and event helpers of libavhot.so.
-#include <mutex>
 #include "common.h"
 
 #include <chrono>
@@ -15,47 +14,6 @@ void av_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
-}
-
-namespace {
-std::mutex g_pool_mu;
-std::vector<hipStream_t> g_stream_pool[64][2];      // [device][0 normal, 1 lowest priority]
-}  // namespace
-
-hipStream_t av_pool_stream_get(int device, bool low_priority) {
-    if (device < 0 || device >= 64) {
-        av_set_error("av_pool_stream_get: device %d", device);
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    std::vector<hipStream_t>& pool = g_stream_pool[device][low_priority ? 1 : 0];
-    if (pool.empty()) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const int n = low_priority ? 2 : 4;            // a batch: consecutive creations land on different hardware queues
-        for (int i = 0; i < n; ++i) {
-            hipStream_t s = nullptr;
-            const hipError_t e = low_priority ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least)
-                                              : hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-            if (e != hipSuccess) {
-                av_set_error("hipStreamCreate -> %s", hipGetErrorString(e));
-                break;
-            }
-            pool.insert(pool.begin(), s);             // (handed out in creation order: back() is the oldest)
-        }
-        if (pool.empty()) return nullptr;
-    }
-    hipStream_t s = pool.back();
-    pool.pop_back();
-    return s;
-}
-
-void av_pool_stream_put(int device, hipStream_t s, bool low_priority) {
-    if (!s) return;
-    (void)hipStreamSynchronize(s);
-    if (device < 0 || device >= 64) return;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_stream_pool[device][low_priority ? 1 : 0].push_back(s);
 }
 
 extern "C" {
@@ -95,8 +53,7 @@ int av_ctx_create(int device, av_ctx** out) {
     av_ctx* c = new (std::nothrow) av_ctx();
     AV_REQUIRE(c, AV_ENOMEM, "av_ctx_create: out of host memory");
     c->device = device;
-    c->side = av_pool_stream_get(device);
-    AV_REQUIRE(c->side, AV_EHIP, "av_ctx_create: no side stream");
+    AV_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     AV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     AV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     // class cdf of the simulated detector (detector.py:159; legacy RandomState.choice: cumsum, /= last)
@@ -134,7 +91,7 @@ int av_ctx_destroy(av_ctx* ctx) {
     if (ctx->d_simtab) (void)hipFree(ctx->d_simtab);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    av_pool_stream_put(ctx->device, ctx->side);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     delete ctx;
     return AV_OK;
 }

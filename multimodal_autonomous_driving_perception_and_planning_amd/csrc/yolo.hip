@@ -2486,8 +2486,8 @@ size_t av_yolo_param_count(void) {
 int av_yolo_destroy(av_yolo* h) {
     if (!h) return AV_OK;
     for (void* p : h->y.allocs) (void)hipFree(p);
-    av_pool_stream_put(h->y.ctx ? h->y.ctx->device : -1, h->y.side);      // (streams go back to the process-wide pool, common.h)
-    av_pool_stream_put(h->y.ctx ? h->y.ctx->device : -1, h->y.tail, true);
+    if (h->y.side) (void)hipStreamDestroy(h->y.side);
+    if (h->y.tail) (void)hipStreamDestroy(h->y.tail);
     if (h->y.ev_heads) (void)hipEventDestroy(h->y.ev_heads);
     if (h->y.ev_decoded) (void)hipEventDestroy(h->y.ev_decoded);
     if (h->y.ev_tail) (void)hipEventDestroy(h->y.ev_tail);
@@ -2592,8 +2592,7 @@ int av_yolo_create_ex(av_ctx* ctx, int batch, int in_h, int in_w, const float* w
         return AV_EINVAL;
     }
     if (!getenv("AVHOT_YOLO_SERIAL")) {
-        y.side = av_pool_stream_get(ctx->device);
-        AV_REQUIRE(y.side, AV_EHIP, "av_yolo_create: no side stream");
+        AV_HIP(hipStreamCreateWithFlags(&y.side, hipStreamNonBlocking));
         AV_HIP(hipEventCreateWithFlags(&y.ev_fork, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&y.ev_join, hipEventDisableTiming));
     }
@@ -2946,8 +2945,7 @@ int av_yolo_defer_tail(av_yolo* h, int enable) {
     AV_REQUIRE(h, AV_EINVAL, "av_yolo_defer_tail: null handle");
     Yolo& y = h->y;
     if (enable && !y.tail) {
-        y.tail = av_pool_stream_get(y.ctx->device, true);      // off the critical path: a lowest-priority stream (own queue class)
-        AV_REQUIRE(y.tail, AV_EHIP, "av_yolo_defer_tail: no stream");
+        AV_HIP(hipStreamCreateWithFlags(&y.tail, hipStreamNonBlocking));
         AV_HIP(hipEventCreateWithFlags(&y.ev_heads, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&y.ev_decoded, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&y.ev_tail, hipEventDisableTiming));

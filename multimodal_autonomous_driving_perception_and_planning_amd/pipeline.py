@@ -69,8 +69,7 @@ class HotLoop:
                    if keep_waypoints else None)
         self.cost = torch.zeros(S * W, self.n_cand, dtype=f64, device=d)
         self.order = torch.zeros(S * W, self.n_cand, dtype=i32, device=d)
-        # main chain on a highest-priority stream: a hardware-queue class of its own, never shared with the library's side streams
-        self.stream = torch.cuda.Stream(device=d, priority=-1)
+        self.stream = torch.cuda.Stream(device=d)
         self.graph_id = None
         self._graphs = {}
         can_fuse = window == 1 and tcap == 64 and 7 <= dcap <= 8 and self.tcfg.iou_threshold > 0
