@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
                     help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
     ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step")
+    ap.add_argument("--no-tune", action="store_true", help="config3: keep the first main stream (no PerceptionLoop.tune_streams())")
     ap.add_argument("--taggers", action="store_true",
                     help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
@@ -446,6 +447,10 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6, precision
     mfma_peak = MFMA_F32_PEAK_TFLOPS if fp32 else MFMA_PEAK_TFLOPS
     if not a.no_defer and not fp32:
         loop.defer_detector_tail(True)       # decode + sort + NMS of step k beside the convolutions of step k+1
+    # which hardware queues the runtime gave the step's four streams decides how its chains overlap (1.55 or 2.9 ms per step for the
+    # same work, depending on the process's stream history): the loop measures a few candidate main streams and keeps the best
+    tuned = loop.tune_streams() if (not a.no_defer and not a.no_tune) else None
+    s = loop._s
 
     def one_step():
         # PerceptionLoop.step_deferred(): the lane chain runs beside the detector on the side stream (both only read
@@ -537,7 +542,8 @@ def run_config3(a, world, rank, local, S, steps, warmup, stage_reps=6, precision
            "scaling": "weak", "vs_baseline": None, "dtype": loop.yolo.precision, "data": "synthetic (generated on device)",
            "config": {"workload": "config3: %d camera streams/GPU, one 1280x720 frame of each per step, YOLO-mode detector "
                                   "(random-init YOLOv8n topology, letterbox 384x640%s) + Canny/Hough lane detector" % (S, ", float32 operands: the reference's own precision" if fp32 else ", IEEE-half operands"),
-                      "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world},
+                      "streams_per_gpu": S, "parallelism": "stream-sharded x%d" % world,
+                      "main_stream_candidates_ms": tuned},
            "roofline": roof, "kernels": finish_kernel_list(ks),
            "lane_chain": {"avg_ms": round(lane_ms, 5), "bytes_per_launch": lane_total,
                           "achieved": round(lane_total / (lane_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

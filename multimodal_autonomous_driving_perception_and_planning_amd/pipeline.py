@@ -332,6 +332,7 @@ class PerceptionLoop:
                                    "finalize_fast + compact_box")
         self.frame_idx = 0
         self._lanes_pending = False
+        self._tail_deferred = False
         self.stream.synchronize()
 
     @property
@@ -367,12 +368,50 @@ class PerceptionLoop:
         if sync:
             self.stream.synchronize()
 
+    def tune_streams(self, candidates=8, steps=4):
+        """Pick the main stream the step overlaps best on.  A step is four chains on four streams (detector main chain, Detect
+        head's class branch, lane chain, deferred detector tail); the HIP runtime serves a process's streams from a few hardware
+        queues per priority class, assigned by the process's whole stream history, and WHICH queues the four chains got decides
+        how they overlap -- measured on MI355X / ROCm 7.2: the same 64-camera step takes 1.55 ms or 2.9 ms (tools/c3seq.py: fresh
+        process 1.55; after any HotLoop was closed 2.9; with four more highest-priority streams created first 1.55 again).  The
+        runtime offers no way to ask for a queue, so the loop measures: `steps` pipelined steps on each of `candidates`
+        highest-priority streams (PyTorch hands its pool out round-robin), keeps the fastest.  Results do not depend on the
+        stream; the generator's frame counter and the lanes' EMA state are put back afterwards.  -> ms per step of every candidate."""
+        import time
+        state0, idx0 = self.lane_state.clone(), self.frame_idx
+        deferred = bool(self._tail_deferred)
+        self.synchronize()
+        tried = []
+        for _ in range(max(1, candidates)):
+            st = torch.cuda.Stream(device=self.dev, priority=-1)
+            self.stream = st
+            self._lanes_pending = False
+            for _ in range(2):
+                self.step_deferred()
+            self.flush_lanes()
+            self.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step_deferred()
+            self.flush_lanes()
+            self.synchronize()
+            tried.append(((time.perf_counter() - t0) / steps * 1e3, st))
+        best = min(tried, key=lambda x: x[0])
+        self.stream = best[1]
+        self._lanes_pending = False
+        self.lane_state.copy_(state0)
+        self.frame_idx = idx0
+        self.synchronize()
+        self.defer_detector_tail(deferred)
+        return [round(t, 4) for t, _ in tried]
+
     def defer_detector_tail(self, enable=True):
         """Throughput mode of the detector: decode + sort + NMS of step k beside the convolutions of step k+1
         (av_yolo_defer_tail); det_* are complete after flush_lanes() / join_detector_tail()."""
         if enable and self.yolo.precision == "fp32":
             raise RuntimeError("the float32 detector mode has no deferred tail")
         nat.check(self.L.av_yolo_defer_tail(self.yolo._h, 1 if enable else 0))
+        self._tail_deferred = bool(enable)
 
     def join_detector_tail(self):
         nat.check(self.L.av_yolo_join_tail(self.yolo._h, self._s))
