@@ -71,8 +71,17 @@ class ObjectDetector:
     def _detect_yolo(self, frame):
         boxes, conf, cls = self.model.detect(frame)
         names = self.model.names
-        return [Detection(bbox=tuple(int(v) for v in b), class_id=int(k), class_name=names.get(int(k), "unknown"),
-                          confidence=float(c)) for b, c, k in zip(boxes, conf, cls)]
+        # int() of every coordinate (detector.py:111: truncation toward zero), float() of every confidence, the box centre of
+        # Detection.__post_init__ -- for up to 300 boxes: as array operations, then plain attribute stores (a random-init network keeps
+        # max_det = 300 boxes per frame; 300 dataclass constructions over NumPy scalars were 0.4 ms of a 1.1-ms call)
+        bi = boxes.astype(np.int64)
+        cx, cy = ((bi[:, 0] + bi[:, 2]) / 2).tolist(), ((bi[:, 1] + bi[:, 3]) / 2).tolist()
+        out, new = [], object.__new__
+        for b, k, c, x, y in zip(bi.tolist(), cls.tolist(), conf.astype(np.float64).tolist(), cx, cy):
+            d = new(Detection)
+            d.bbox, d.class_id, d.class_name, d.confidence, d.center = (b[0], b[1], b[2], b[3]), k, names.get(k, "unknown"), c, (x, y)
+            out.append(d)
+        return out
 
     def _detect_simulated(self, frame) -> List[Detection]:
         h, w = frame.shape[:2]
