@@ -2263,6 +2263,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     __shared__ float bfx[HB], bfy[HB];
     __shared__ int row_sz[HQ * HTL];
     __shared__ unsigned long long ebits[2][HS_EB];             // live pixels found (and cleared) by the two directions of an erase
+    __shared__ unsigned tu_cnt[256];                           // top-up: how many of a top-up's draws fall on a position class (idx & 255)
     __shared__ unsigned sh_hit[HVW], sh_key[HVW];
     __shared__ int sh_nb, sh_head, sh_tail, sh_count, sh_big, sh_hits, sh_fail, sh_er[8];
     // Workgroups go round-robin over the 8 XCDs (blockIdx % 8): the four workgroups of a frame are given the same blockIdx % 8, so that
@@ -2297,6 +2298,7 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
     // the LDS clears do not depend on the point list: they run while its loads are in flight
     for (int i = (int)threadIdx.x; i < HVW * HS_ACCW; i += NTH) (&acc_all[0][0])[i] = HS_BIAS | (HS_BIAS << 16);
     for (int i = (int)threadIdx.x; i < HS_BMW; i += NTH) bm[i] = 0;
+    for (int i = (int)threadIdx.x; i < 256; i += NTH) tu_cnt[i] = 0;
     if (total > HS_NZ) {                                                                  // same verdict in all HG workgroups (and every wave)
         give_up();
         return;
@@ -2440,12 +2442,25 @@ __global__ void __launch_bounds__((HVW + 1) * 64) houghp_shard(int h, int w, int
         // Resolved in registers instead: what position p holds at step k is what the ORIGINAL array holds at the
         // position found by chasing p backwards through the earlier steps that wrote it.  The low half-wave does
         // that for the picks, the high half for the elements moved in; only the last writer of a position stores.
+        // Round 4: a step j can redirect anybody's chase only if idx_j equals another draw's index or lies in the tail region
+        // [cnt - nd, cnt) the moved-in elements come from -- otherwise idx_j matches no chased position at all.  Those steps are
+        // found first (a 256-entry count table over idx & 255: a count above one flags every draw of a class that holds a
+        // duplicate, and a few innocent ones) and the chase visits only them, in the original descending order: typically 3-6
+        // steps instead of 32 (round 3's 32-step loop was ~3 000 cycles per top-up, and a frame draws ALL its points).
         const int idx = kk < nd ? (int)(r_mine % (unsigned)(cnt - kk)) : -1;
+        const bool drawer = lane < HB && kk < nd;
+        if (drawer) atomicAdd(&tu_cnt[idx & 255], 1u);
+        lds_order();
+        const bool involved = drawer && (tu_cnt[idx & 255] > 1u || idx >= cnt - nd);
+        unsigned hot = (unsigned)__ballot(involved);              // (low half-wave: bit = draw index)
+        lds_order();
+        if (drawer) atomicSub(&tu_cnt[idx & 255], 1u);
         int p = lane < HB ? idx : cnt - 1 - kk;
         bool last_writer = true;
-#pragma unroll
-        for (int k2 = HB - 1; k2 >= 0; --k2) {
-            const int ik = __builtin_amdgcn_readlane(idx, k2);       // -1 beyond nd: matches nothing
+        while (hot) {
+            const int k2 = 31 - __clz((int)hot);
+            hot &= ~(1u << k2);
+            const int ik = __builtin_amdgcn_readlane(idx, k2);
             if (k2 < kk && ik == p) p = cnt - 1 - k2;
             if (k2 > kk && ik == idx) last_writer = false;
         }
