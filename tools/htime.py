@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the sharded PPHT kernel's time goes: AVHOT_HOUGH_TIMED=1 makes wave 0 of every frame's first workgroup add up s_memtime
-cycles (100 MHz constant clock on gfx950: 10 ns units) per phase; this prints them per frame and for the slowest frame."""
+cycles (shader clock, ~2.2-2.4 GHz under this load) per phase; this prints kilo-cycles for the slowest frame and the mean frame."""
 import ctypes as C, os, sys
 os.environ["AVHOT_HOUGH_TIMED"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,11 +33,11 @@ for s in range(S):
 rows = np.array(rows)
 tot = rows[:, :9].sum(axis=1)
 k = int(np.argmax(tot))
-print("s_memtime units of 10 ns; 64 frames (8 distinct), slowest frame %d: %.1f us, mean frame %.1f us" % (k, tot[k] / 100, tot.mean() / 100))
+print("s_memtime kilo-cycles; 64 frames (8 distinct), slowest frame %d: %.1f kcyc, mean frame %.1f kcyc" % (k, tot[k] / 1000, tot.mean() / 1000))
 for i, nme in enumerate(names):
     if nme == "-":
         continue
     if i < 9:
-        print("  %-13s slowest %7.1f us (%4.1f %%)   mean %7.1f us" % (nme, rows[k, i] / 100, 100 * rows[k, i] / tot[k], rows[:, i].mean() / 100))
+        print("  %-13s slowest %7.1f kcyc (%4.1f %%)   mean %7.1f kcyc" % (nme, rows[k, i] / 1000, 100 * rows[k, i] / tot[k], rows[:, i].mean() / 1000))
     else:
         print("  %-13s slowest %7d              mean %7.1f" % (nme, rows[k, i], rows[:, i].mean()))
