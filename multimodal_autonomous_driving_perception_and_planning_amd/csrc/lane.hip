@@ -1701,7 +1701,7 @@ __device__ __forceinline__ bool mask_on(const uint8_t* m, size_t i) {
     return *reinterpret_cast<const volatile uint8_t*>(m + i) != 0;
 }
 
-__global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ masked, int h, int w, int numrho,
+__device__ __noinline__ void houghp_generic_body(uint8_t* __restrict__ masked, int h, int w, int numrho,
                                                      HoughCfg cfg, unsigned* __restrict__ nz_all,
                                                      const int* __restrict__ npts, int* __restrict__ accum_all,
                                                      const float* __restrict__ trig, int* __restrict__ segs,
@@ -1876,7 +1876,7 @@ __global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ maske
 // Streams whose points or bitmap do not fit are flagged and handled by houghp_kernel.
 constexpr int HB = 32, NZCAP = 12288, BMWORDS = 16384, FIFO = 128;
 
-__global__ void __launch_bounds__(192) houghp_fast(int h, int w, int numrho, HoughCfg cfg,
+__device__ __noinline__ void houghp_fast_body(int h, int w, int numrho, HoughCfg cfg,
                                                    const unsigned* __restrict__ nz_all, const int* __restrict__ npts,
                                                    int* __restrict__ accum_all, const float* __restrict__ trig,
                                                    int* __restrict__ segs, int* __restrict__ nseg,
@@ -2864,6 +2864,46 @@ __global__ void __launch_bounds__(64) lane_fit_kernel(int S, int h, int w, int m
     pp[2 * lane] = (int)x, pp[2 * lane + 1] = (int)y;
 }
 
+// the generic PPHT kernel alone (stage bit 3: tests of the fallback chain)
+__global__ void __launch_bounds__(192) houghp_kernel(uint8_t* __restrict__ masked, int h, int w, int numrho, HoughCfg cfg,
+                                                     unsigned* __restrict__ nz_all, const int* __restrict__ npts, int* __restrict__ accum_all,
+                                                     const float* __restrict__ trig, int* __restrict__ segs, int* __restrict__ nseg,
+                                                     const int* __restrict__ fallback, int* __restrict__ path, int rebuild_mask) {
+    houghp_generic_body(masked, h, w, numrho, cfg, nz_all, npts, accum_all, trig, segs, nseg, fallback, path, rebuild_mask);
+}
+
+// The end of the lane chain as ONE launch, workgroup = frame: the single-workgroup PPHT for a frame the sharded kernel gave up, the
+// generic PPHT for a frame that one cannot hold either (both leave at once for a frame that is done: the usual case), then the two
+// fits (wave = side).  Three launches of ~4.7 + 4.7 + 9.5 us before.
+__global__ void __launch_bounds__(192) hough_tail_kernel(uint8_t* __restrict__ masked, int h, int w, int numrho, HoughCfg cfg,
+                                                         unsigned* __restrict__ nz_all, const int* __restrict__ npts, int* __restrict__ accum_all,
+                                                         const float* __restrict__ trig, int* __restrict__ segs, int* __restrict__ nseg,
+                                                         int* __restrict__ fallback, int* __restrict__ path, int check_flag, int rebuild_mask,
+                                                         int max_segments, double smoothing, double* __restrict__ lane_state,
+                                                         double* __restrict__ poly, int* __restrict__ pts, int* __restrict__ info,
+                                                         double* __restrict__ conf, const double* __restrict__ thr) {
+    houghp_fast_body(h, w, numrho, cfg, nz_all, npts, accum_all, trig, segs, nseg, fallback, check_flag, path);
+    __threadfence();
+    __syncthreads();
+    houghp_generic_body(masked, h, w, numrho, cfg, nz_all, npts, accum_all, trig, segs, nseg, fallback, path, rebuild_mask);
+    __threadfence();
+    __syncthreads();
+    const int s = blockIdx.x, side = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double coef2[2][4];                                       // c2 c1 c0 valid, per side
+    if (side < 2 && lane == 0) {
+        coef2[side][3] = 0.0;
+        lane_fit_one(s, side, h, w, max_segments, smoothing, segs, nseg, lane_state, poly, info, conf, thr, npts, coef2[side]);
+    }
+    __syncthreads();
+    if (side >= 2 || coef2[side][3] == 0.0 || lane >= 50) return;
+    const double c2 = coef2[side][0], c1 = coef2[side][1], c0 = coef2[side][2];
+    const double ya = (double)h * 0.6, yb = (double)h, step = (yb - ya) / 49.0;
+    int* pp = pts + ((size_t)s * 2 + side) * 100;
+    const double y = lane == 49 ? yb : (double)lane * step + ya;
+    const double x = (c2 * y + c1) * y + c0;
+    pp[2 * lane] = (int)x, pp[2 * lane + 1] = (int)y;
+}
+
 struct LaneCtx {
     float* d_trig = nullptr;
     int* d_roi = nullptr;           // default trapezoid's [xl, xr] per row for frames of roi_h x roi_w (the bit-map resolve path)
@@ -3134,9 +3174,11 @@ int av_lane_detect(av_ctx* ctx, av_stream_t stream, const av_lane_cfg* cfg, int 
                                (getenv("AVHOT_HOUGH_XCD") && atoi(getenv("AVHOT_HOUGH_XCD")) == 0) ? 0 : 1);
             AV_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(houghp_fast, dim3(n_streams), dim3(192), 0, st, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
-                           segs, nseg, fb, use_shard ? 1 : 0, hpath);
+        hipLaunchKernelGGL(hough_tail_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum, lc->d_trig,
+                           segs, nseg, fb, hpath, use_shard ? 1 : 0, rebuild ? 1 : 0, cfg->max_segments, cfg->smoothing_factor, lane_state,
+                           poly, pts, info, conf, thr);
         AV_LAUNCH_CHECK();
+        return AV_OK;
     }
     hipLaunchKernelGGL(houghp_kernel, dim3(n_streams), dim3(192), 0, st, masked, h, w, L.numrho, hc, nz, npts, accum,
                        lc->d_trig, segs, nseg, use_fast ? fb : nullptr, hpath, rebuild ? 1 : 0);
