@@ -2699,12 +2699,20 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         for (const Yolo::Op& op : y.ops) {
             if (op.kind == 10) {
                 const ConvArgsF& a = op.cf;
-                constexpr int NT = 4;
-                const dim3 grid((a.npix + 64 * NT - 1) / (64 * NT), a.cout / (16 * op.mt));
-#define AV_CF(MTV)                                                                                      \
-    do {                                                                                                \
-        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NT, 16>), grid, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((conv_f32_kernel<MTV, NT, 4>), grid, dim3(256), 0, st, a);              \
+                // pixels per wave (16 NT): the small maps need small tiles to fill the chip -- a P5 layer of 64 frames is 15 360 pixels,
+                // 60 workgroups at NT = 4 (160-390 us per layer), 240 at NT = 1
+                const int nt = a.npix >= 200000 ? 4 : (a.npix >= 50000 ? 2 : 1);
+                const dim3 grid((a.npix + 64 * nt - 1) / (64 * nt), a.cout / (16 * op.mt));
+#define AV_CF3(MTV, NTV)                                                                                     \
+    do {                                                                                                     \
+        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 16>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 4>), grid, dim3(256), 0, st, a);                  \
+    } while (0)
+#define AV_CF(MTV)                                                                                           \
+    do {                                                                                                     \
+        if (nt == 4) AV_CF3(MTV, 4);                                                                         \
+        else if (nt == 2) AV_CF3(MTV, 2);                                                                    \
+        else AV_CF3(MTV, 1);                                                                                 \
     } while (0)
                 AV_REQUIRE(a.cin % 16 == 0 || a.cin == 4, AV_EINVAL, "av_yolo_forward: float32 convolution with %d input channels", a.cin);
                 AV_REQUIRE(a.cout == 16 * op.mt * (int)grid.y, AV_EINVAL, "av_yolo_forward: float32 convolution with %d output channels", a.cout);
@@ -2713,6 +2721,7 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                 else if (op.mt == 2) AV_CF(2);
                 else AV_CF(1);
 #undef AV_CF
+#undef AV_CF3
             } else {
                 const Buf &bi = y.bufs[op.in.buf], &bo = y.bufs[op.out.buf];
                 const float* src = reinterpret_cast<const float*>(bi.p);
