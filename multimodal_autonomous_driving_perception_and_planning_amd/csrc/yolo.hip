@@ -1938,9 +1938,10 @@ struct ConvArgsF {
     float* out;       int out_cs, out_coff, cout, Ho, Wo;
     const float* res; int res_cs, res_coff;
     int act, npix;
+    const float* zeros;          // 16 floats of zeros: what a tap outside the image loads (a select behind the load would make every request wait for its data)
 };
 
-template <int MT, int NT, int CB>
+template <int MT, int NT, int CB, int D = 2>     // D: operand blocks in flight (a ring of D register buffers, unrolled: indices are compile-time)
 __global__ void __launch_bounds__(256) conv_f32_kernel(ConvArgsF a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kk = lane >> 4;
     const int p0 = ((int)blockIdx.x * 4 + wave) * (16 * NT), co0 = (int)blockIdx.y * (16 * MT);
@@ -1966,7 +1967,7 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvArgsF a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nblk = a.cin / CB, steps = taps * nblk;
-    f32x4 A[2][MT], Bv[2][NT];
+    f32x4 A[D][MT], Bv[D][NT];
     auto request = [&](int st, int buf) {
         const int tap = st / nblk, c0 = (st - tap * nblk) * CB;
         const int ky = tap / a.ksz, kx = tap - ky * a.ksz;
@@ -1979,24 +1980,29 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvArgsF a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int iy = py[nt] * a.stride + ky - pad, ix = px[nt] * a.stride + kx - pad;
             const bool inb = pv[nt] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const float* src = a.in + ((size_t)(pb[nt] * a.H + (inb ? iy : 0)) * a.W + (inb ? ix : 0)) * a.in_cs + a.in_coff + c0 + (CB == 16 ? 4 * kk : kk);
-            f32x4 v;
-            if (CB == 16) v = *reinterpret_cast<const f32x4*>(src);
-            else v = f32x4{*src, 0.f, 0.f, 0.f};
-            Bv[buf][nt] = inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* src = inb ? a.in + ((size_t)(pb[nt] * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + c0 + (CB == 16 ? 4 * kk : kk) : a.zeros;
+            if (CB == 16) Bv[buf][nt] = *reinterpret_cast<const f32x4*>(src);
+            else Bv[buf][nt] = f32x4{*src, 0.f, 0.f, 0.f};
         }
     };
-    request(0, 0);
-    for (int st = 0; st < steps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < steps) request(st + 1, cur ^ 1);
 #pragma unroll
-        for (int s4 = 0; s4 < (CB == 16 ? 4 : 1); ++s4)
+    for (int d = 0; d < D - 1; ++d)
+        if (d < steps) request(d, d);
+    for (int st0 = 0; st0 < steps; st0 += D) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int d = 0; d < D; ++d) {
+            const int st = st0 + d;
+            if (st + D - 1 < steps) request(st + D - 1, (d + D - 1) % D);      // the block D - 1 steps ahead, into the buffer consumed last trip
+            if (st < steps) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][mt][s4], Bv[cur][nt][s4], acc[mt][nt], 0, 0, 0);
+                for (int s4 = 0; s4 < (CB == 16 ? 4 : 1); ++s4)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[d][mt][s4], Bv[d][nt][s4], acc[mt][nt], 0, 0, 0);
+            }
+        }
     }
     // D[i = 4 (lane / 16) + r][j = lane % 16]: four consecutive output channels of pixel j per lane
 #pragma unroll
@@ -2077,6 +2083,7 @@ struct Yolo {
     int B = 0, inH = 0, inW = 0, H = 0, W = 0, nh = 0, nw = 0, top = 0, left = 0, A = 0, words = 0;
     float gain = 1.f;
     std::vector<Buf> bufs;
+    float* f32_zeros = nullptr;
     bool f32 = false;                    // reference-precision mode: float32 tensors and weights, conv_f32_kernel, no fusion
     struct Op { int kind; ConvArgs ca; ConvArgsF cf; int mt; Slice in, out; int H, W, C; int lane = 0; int fuse = 0; int dec = 0, dec_level = 0; int vcat = -1; };   // lane 1: internal side stream;
     // vcat >= 0 (an upsample op): op index of the 1x1 convolution that can read this upsample's source directly (virtual Upsample + Concat);
@@ -2169,6 +2176,8 @@ bool add_conv(Yolo& y, Slice in, Slice out, int k, int s, bool bn_act, float* ou
         a.res = nullptr, a.res_cs = 0, a.res_coff = 0;
         if (res) a.res = reinterpret_cast<const float*>(y.bufs[res->buf].p), a.res_cs = y.bufs[res->buf].C, a.res_coff = res->coff;
         a.act = bn_act ? 1 : 0, a.npix = y.B * a.Ho * a.Wo;
+        if (!y.f32_zeros && !dev_alloc(y, (void**)&y.f32_zeros, 64)) return false;      // (dev_alloc clears)
+        a.zeros = y.f32_zeros;
         op.mt = (cout % 64 == 0) ? 4 : ((cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1));
         y.ops.push_back(op);
         return true;
@@ -2705,8 +2714,8 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                 const dim3 grid((a.npix + 64 * nt - 1) / (64 * nt), a.cout / (16 * op.mt));
 #define AV_CF3(MTV, NTV)                                                                                     \
     do {                                                                                                     \
-        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 16>), grid, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 4>), grid, dim3(256), 0, st, a);                  \
+        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 16, (NTV == 4 ? 2 : 4)>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 4, 2>), grid, dim3(256), 0, st, a);               \
     } while (0)
 #define AV_CF(MTV)                                                                                           \
     do {                                                                                                     \
