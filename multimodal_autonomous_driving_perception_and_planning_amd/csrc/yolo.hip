@@ -2710,11 +2710,12 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
                 const ConvArgsF& a = op.cf;
                 // pixels per wave (16 NT): the small maps need small tiles to fill the chip -- a P5 layer of 64 frames is 15 360 pixels,
                 // 60 workgroups at NT = 4 (160-390 us per layer), 240 at NT = 1
-                const int nt = a.npix >= 200000 ? 4 : (a.npix >= 50000 ? 2 : 1);
+                // (80 output channels at NT = 4 take 186 registers -- one wave per SIMD: NT = 2 there)
+                const int nt = a.npix >= 200000 ? (op.mt == 5 ? 2 : 4) : (a.npix >= 50000 ? 2 : 1);
                 const dim3 grid((a.npix + 64 * nt - 1) / (64 * nt), a.cout / (16 * op.mt));
 #define AV_CF3(MTV, NTV)                                                                                     \
     do {                                                                                                     \
-        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 16, (NTV == 4 ? 2 : 4)>), grid, dim3(256), 0, st, a); \
+        if (a.cin % 16 == 0) hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 16, (NTV == 4 ? 3 : 4)>), grid, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((conv_f32_kernel<MTV, NTV, 4, 2>), grid, dim3(256), 0, st, a);               \
     } while (0)
 #define AV_CF(MTV)                                                                                           \
