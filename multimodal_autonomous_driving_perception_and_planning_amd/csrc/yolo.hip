@@ -2024,6 +2024,110 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(ConvArgsF a) {
     }
 }
 
+// conv_gemm_f32_kernel<AR, BR, KC>: the float32 convolutions with 64 / 80 / 128 / 256 output channels as LDS-tiled GEMMs over flattened
+// output pixels -- conv_gemm128_kernel's structure with float32 slabs.  A workgroup of four waves owns AR output channels x BR
+// pixels (128 x 64: wave = 64 channels x 32 pixels, two across two; 64 x 128 and 80 x 128: every wave all channels x its 32 pixels)
+// and walks K in steps of KC = 32 (or 16: cin = 80) channels of one tap through double-buffered LDS slabs (rows of KC floats + 32
+// bytes: = 32 mod 64); a step's 16-byte pieces are requested a whole step ahead, before the MFMAs; taps outside the image come from
+// the zero page.  MFMA operands: lane group h reads the float4 at channel 4 h of each 16-channel block (ds_read_b128) and uses it for
+// four v_mfma_f32_16x16x4_f32 steps -- the same K permutation on both operands as in conv_f32_kernel.
+template <int AR, int BR, int KC>
+__global__ void __launch_bounds__(256) conv_gemm_f32_kernel(ConvArgsF a) {
+    constexpr int ROWB = KC * 4 + 32, PCS = KC / 4;              // bytes per LDS row; 16-byte pieces per row
+    constexpr int MT = AR == 128 ? 4 : AR / 16, NT = 2;          // wave tile: 16 MT channels x 32 pixels
+    // pieces per thread and step: a divisor of the pieces per row (a thread's pieces stay inside one row); 80 rows use 160 threads
+    constexpr int NA = AR == 64 ? PCS / 4 : PCS / 2, NB = BR == 64 ? PCS / 4 : PCS / 2;
+    static_assert(NA >= 1 && NB >= 1 && PCS % NA == 0 && PCS % NB == 0 && AR * PCS <= 256 * NA && BR * PCS == 256 * NB, "staging shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char cgf_smem[];
+    unsigned char* As = cgf_smem;                                 // [2][AR rows]
+    unsigned char* Bs = cgf_smem + 2 * AR * ROWB;                 // [2][BR rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
+    const int wm = AR == 128 ? (wave & 1) : 0, wn = AR == 128 ? (wave >> 1) : wave;
+    const int pix_base = blockIdx.x * BR, ch_base = blockIdx.y * AR;
+    const int taps = a.ksz * a.ksz, K = taps * a.cin, pad = a.ksz >> 1;
+    // ---- what this thread stages per step: NA pieces of one weight row, NB pieces of one pixel's channels -----------------------
+    const int aq0 = tid * NA, arow_s = aq0 / PCS, apc = aq0 - arow_s * PCS;
+    const bool a_on = arow_s < AR;
+    const float* wsrc = a.wgt + (size_t)(ch_base + (a_on ? arow_s : 0)) * K + apc * 4;
+    const int bq0 = tid * NB, brow_s = bq0 / PCS, bpc = bq0 - brow_s * PCS;
+    const int sp = pix_base + brow_s;
+    const bool spv = sp < a.npix;
+    const int spp = spv ? sp : 0;
+    const int sn = spp / (a.Ho * a.Wo), sr = spp - sn * a.Ho * a.Wo, soy = sr / a.Wo, sox = sr - soy * a.Wo;
+    const int iy0 = soy * a.stride - pad, ix0 = sox * a.stride - pad;
+    f32x4 ra[NA], rb[NB];
+    const int SPT = a.cin / KC, NSTEP = taps * SPT;
+    auto gload = [&](int st) {
+        const int tap = st / SPT, part = st - tap * SPT, ky = tap / a.ksz, kx = tap - ky * a.ksz;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wsrc + (size_t)tap * a.cin + part * KC);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) ra[q] = wp[q];
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = spv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const float* src = ok ? a.in + ((size_t)(sn * a.H + iy) * a.W + ix) * a.in_cs + a.in_coff + part * KC + bpc * 4 : a.zeros;
+        const f32x4* bp = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) rb[q] = bp[ok ? q : 0];              // (zero page: 16 floats)
+    };
+    auto lstore = [&](int buf) {
+        if (a_on) {
+            f32x4* da = reinterpret_cast<f32x4*>(As + (size_t)(buf * AR + arow_s) * ROWB + apc * 16);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) da[q] = ra[q];
+        }
+        f32x4* db = reinterpret_cast<f32x4*>(Bs + (size_t)(buf * BR + brow_s) * ROWB + bpc * 16);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) db[q] = rb[q];
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    lstore(0);
+    if (NSTEP > 1) gload(1);
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+        __syncthreads();                           // the step's slab is in LDS; the other buffer's readers (step - 1) are done
+        const unsigned char* arow = As + (size_t)((st & 1) * AR + wm * 64 + l15) * ROWB + 16 * h;
+        const unsigned char* brow = Bs + (size_t)((st & 1) * BR + wn * 32 + l15) * ROWB + 16 * h;
+        if (st + 1 < NSTEP) lstore((st + 1) & 1);    // requested a whole step ago
+        if (st + 2 < NSTEP) gload(st + 2);           // in flight during this step's MFMAs
+#pragma unroll
+        for (int c = 0; c < KC / 16; ++c) {
+            f32x4 A[MT], B[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const f32x4*>(arow + mt * 16 * ROWB + c * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const f32x4*>(brow + nt * 16 * ROWB + c * 64);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt][s4], B[nt][s4], acc[mt][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int pi = pix_base + wn * 32 + nt * 16 + l15;
+        if (pi >= a.npix) continue;
+        const size_t p = (size_t)pi;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = ch_base + wm * 64 + mt * 16 + 4 * h;
+            f32x4 v = acc[mt][nt] + *reinterpret_cast<const f32x4*>(a.bias + co);
+            if (a.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-v[r]));          // SiLU = x * sigmoid(x)
+            }
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.res_cs + a.res_coff + co);
+            *reinterpret_cast<f32x4*>(a.out + p * a.out_cs + a.out_coff + co) = v;
+        }
+    }
+}
+
 // letterbox + bilinear resize + BGR -> RGB + / 255 -> NHWC4 float (channel 3 zero), [B][H][W][4]: preprocess_kernel's arithmetic
 __global__ void preprocess_f32_kernel(const uint8_t* __restrict__ bgr, int B, int h, int w, int H, int W, int nh, int nw,
                                       int top, int left, float* __restrict__ out) {
@@ -2629,6 +2733,12 @@ int av_yolo_create_ex(av_ctx* ctx, int batch, int in_h, int in_w, const float* w
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 64, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<128, 64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<64, 128, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<80, 128, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<128, 64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<64, 128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<80, 128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
 #define AV_WS_ATTR1(MTV, NTV, NWV, CP) \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<MTV, NTV, NWV, CP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
@@ -2708,6 +2818,19 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         for (const Yolo::Op& op : y.ops) {
             if (op.kind == 10) {
                 const ConvArgsF& a = op.cf;
+                // the layers with 64 / 80 / 128 / 256 output channels (all but the stem and the first two blocks): LDS-tiled GEMM form
+                if ((a.cout % 128 == 0 || a.cout == 64 || a.cout == 80) && a.cin % 16 == 0 && !getenv("AVHOT_F32_DIRECT")) {
+                    const bool k32 = a.cin % 32 == 0;
+#define AV_GF(ARV, BRV, KCV)                                                                                                       \
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<ARV, BRV, KCV>), dim3((a.npix + BRV - 1) / BRV, a.cout / ARV), dim3(256),             \
+                       (size_t)2 * (ARV + BRV) * (KCV * 4 + 32), st, a)
+                    if (a.cout % 128 == 0) { if (k32) AV_GF(128, 64, 32); else AV_GF(128, 64, 16); }
+                    else if (a.cout == 64) { if (k32) AV_GF(64, 128, 32); else AV_GF(64, 128, 16); }
+                    else { if (k32) AV_GF(80, 128, 32); else AV_GF(80, 128, 16); }
+#undef AV_GF
+                    AV_LAUNCH_CHECK();
+                    continue;
+                }
                 // pixels per wave (16 NT): the small maps need small tiles to fill the chip -- a P5 layer of 64 frames is 15 360 pixels,
                 // 60 workgroups at NT = 4 (160-390 us per layer), 240 at NT = 1
                 // (80 output channels at NT = 4 take 186 registers -- one wave per SIMD: NT = 2 there)
