@@ -2036,7 +2036,8 @@ __global__ void __launch_bounds__(256) conv_gemm_f32_kernel(ConvArgsF a) {
     constexpr int ROWB = KC * 4 + 32, PCS = KC / 4;              // bytes per LDS row; 16-byte pieces per row
     constexpr int MT = AR == 128 ? 4 : AR / 16, NT = 2;          // wave tile: 16 MT channels x 32 pixels
     // pieces per thread and step: a divisor of the pieces per row (a thread's pieces stay inside one row); 80 rows use 160 threads
-    constexpr int NA = AR == 64 ? PCS / 4 : PCS / 2, NB = BR == 64 ? PCS / 4 : PCS / 2;
+    // (16 / 32 rows: one piece per thread, the first 16 PCS / 32 PCS threads)
+    constexpr int NA = AR <= 32 ? 1 : (AR == 64 ? PCS / 4 : PCS / 2), NB = BR == 64 ? PCS / 4 : PCS / 2;
     static_assert(NA >= 1 && NB >= 1 && PCS % NA == 0 && PCS % NB == 0 && AR * PCS <= 256 * NA && BR * PCS == 256 * NB, "staging shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char cgf_smem[];
     unsigned char* As = cgf_smem;                                 // [2][AR rows]
@@ -2818,14 +2819,16 @@ int av_yolo_forward(av_yolo* h, av_stream_t stream, const uint8_t* bgr, float co
         for (const Yolo::Op& op : y.ops) {
             if (op.kind == 10) {
                 const ConvArgsF& a = op.cf;
-                // the layers with 64 / 80 / 128 / 256 output channels (all but the stem and the first two blocks): LDS-tiled GEMM form
-                if ((a.cout % 128 == 0 || a.cout == 64 || a.cout == 80) && a.cin % 16 == 0 && !getenv("AVHOT_F32_DIRECT")) {
+                // every layer but the stem (cin = 4): LDS-tiled GEMM form
+                if ((a.cout % 128 == 0 || a.cout == 64 || a.cout == 80 || a.cout == 32 || a.cout == 16) && a.cin % 16 == 0 && !getenv("AVHOT_F32_DIRECT")) {
                     const bool k32 = a.cin % 32 == 0;
 #define AV_GF(ARV, BRV, KCV)                                                                                                       \
     hipLaunchKernelGGL((conv_gemm_f32_kernel<ARV, BRV, KCV>), dim3((a.npix + BRV - 1) / BRV, a.cout / ARV), dim3(256),             \
                        (size_t)2 * (ARV + BRV) * (KCV * 4 + 32), st, a)
                     if (a.cout % 128 == 0) { if (k32) AV_GF(128, 64, 32); else AV_GF(128, 64, 16); }
                     else if (a.cout == 64) { if (k32) AV_GF(64, 128, 32); else AV_GF(64, 128, 16); }
+                    else if (a.cout == 32) { if (k32) AV_GF(32, 128, 32); else AV_GF(32, 128, 16); }
+                    else if (a.cout == 16) { if (k32) AV_GF(16, 128, 32); else AV_GF(16, 128, 16); }
                     else { if (k32) AV_GF(80, 128, 32); else AV_GF(80, 128, 16); }
 #undef AV_GF
                     AV_LAUNCH_CHECK();
