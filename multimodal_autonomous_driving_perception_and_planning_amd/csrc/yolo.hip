@@ -286,107 +286,6 @@ __global__ void __launch_bounds__(256) conv_gemm128_kernel(ConvArgs a) {
     }
 }
 
-// conv_gemm64_kernel<AR>: the GEMM form for 64 / 80 output channels -- the Detect head's first convolutions at P4 / P5 (cin 128 / 256,
-// K = 1152 / 2304), which conv_lds_kernel walked chunk by chunk (33-39 us each).  Same slabs, steps and pipeline as conv_gemm128_kernel
-// with the tile turned: four waves own AR output channels x 128 pixels (every wave all channels x its 32 pixels).  AR = 80: the
-// first 160 threads stage the weight rows.  K order = conv_gemm128_kernel's (tap-major, 64 channels per step).
-template <int AR>
-__global__ void __launch_bounds__(256) conv_gemm64_kernel(ConvArgs a) {
-    constexpr int BR = 128, MT = AR / 16, NT = 2;
-    constexpr int NA = AR == 64 ? 2 : 4, NB = 4;              // 16-byte pieces per thread and step (8 per 128-byte row)
-    static_assert(AR == 64 || AR == 80, "tile");
-    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
-    unsigned char* As = cg_smem;                              // [2][AR rows]
-    unsigned char* Bs = cg_smem + 2 * AR * CG_ROWB;           // [2][BR rows]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, h = lane >> 4;
-    const int pix_base = blockIdx.x * BR, ch_base = blockIdx.y * AR;
-    const int aq0 = tid * NA, arow_s = aq0 >> 3, apc = aq0 & 7;
-    const bool a_on = arow_s < AR;
-    const half_t* wsrc = a.wgt + (size_t)(ch_base + (a_on ? arow_s : 0)) * a.kpad + apc * 8;
-    const int bq0 = tid * NB, brow_s = bq0 >> 3, bpc = bq0 & 7;
-    const int sp = pix_base + brow_s;
-    const bool spv = sp < a.npix;
-    const int spp = spv ? sp : 0;
-    const int sn = spp / (a.Ho * a.Wo), sr = spp - sn * a.Ho * a.Wo, soy = sr / a.Wo, sox = sr - soy * a.Wo;
-    const int pad = a.ksz >> 1;
-    const int iy0 = soy * a.stride - pad, ix0 = sox * a.stride - pad;
-    uint4 ra[NA], rb[NB];
-    unsigned rm = 0;
-    const int SPT = a.cin / CG_SC, NSTEP = a.ksz * a.ksz * SPT;
-    auto gload = [&](int st) {
-        const int tap = st / SPT, part = st - tap * SPT, ky = a.ksz == 3 ? tap / 3 : 0, kx = tap - ky * 3;
-        const uint4* wp = reinterpret_cast<const uint4*>(wsrc + (size_t)st * CG_SC);
-#pragma unroll
-        for (int q = 0; q < NA; ++q) ra[q] = wp[q];
-        const int iy = iy0 + ky, ix = ix0 + kx;
-        const bool ok = spv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const int cy = ok ? iy : 0, cx = ok ? ix : 0;       // (clamped when outside: always readable; zeroed on the way into LDS)
-        const uint4* bp = reinterpret_cast<const uint4*>(a.in + ((size_t)(sn * a.H + cy) * a.W + cx) * a.in_cs + a.in_coff + part * CG_SC + bpc * 8);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) rb[q] = bp[q];
-        rm = ok ? ~0u : 0u;
-    };
-    auto lstore = [&](int buf) {
-        if (a_on) {
-            uint4* da = reinterpret_cast<uint4*>(As + (size_t)(buf * AR + arow_s) * CG_ROWB + apc * 16);
-#pragma unroll
-            for (int q = 0; q < NA; ++q) da[q] = ra[q];
-        }
-        uint4* db = reinterpret_cast<uint4*>(Bs + (size_t)(buf * BR + brow_s) * CG_ROWB + bpc * 16);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) db[q] = make_uint4(rb[q].x & rm, rb[q].y & rm, rb[q].z & rm, rb[q].w & rm);
-    };
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 bsv[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bsv[mt] = *reinterpret_cast<const float4*>(a.bias + ch_base + mt * 16 + 4 * h);
-    gload(0);
-    lstore(0);
-    if (NSTEP > 1) gload(1);
-#pragma unroll 1
-    for (int st = 0; st < NSTEP; ++st) {
-        __syncthreads();
-        const unsigned char* arow = As + (size_t)((st & 1) * AR + l15) * CG_ROWB + 16 * h;
-        const unsigned char* brow = Bs + (size_t)((st & 1) * BR + wave * 32 + l15) * CG_ROWB + 16 * h;
-        if (st + 1 < NSTEP) lstore((st + 1) & 1);
-        if (st + 2 < NSTEP) gload(st + 2);
-#pragma unroll
-        for (int c = 0; c < CG_SC / 32; ++c) {
-            half8 A[MT], B[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) A[mt] = *reinterpret_cast<const half8*>(arow + mt * 16 * CG_ROWB + c * 64);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) B[nt] = *reinterpret_cast<const half8*>(brow + nt * 16 * CG_ROWB + c * 64);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(bsv[mt].x), "v"(bsv[mt].y), "v"(bsv[mt].z), "v"(bsv[mt].w));
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int ch = ch_base + mt * 16 + 4 * h;
-        const float4 bs = bsv[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int pi = pix_base + wave * 32 + nt * 16 + l15;
-            if (pi >= a.npix) continue;
-            const size_t p = (size_t)pi;
-            float v[4] = {acc[mt][nt][0] + bs.x, acc[mt][nt][1] + bs.y, acc[mt][nt][2] + bs.z, acc[mt][nt][3] + bs.w};
-            if (a.act)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
-            *reinterpret_cast<half4*>(a.out + p * a.out_cs + a.out_coff + ch) = make_half4(v[0], v[1], v[2], v[3]);
-        }
-    }
-}
-
 // LDS-tiled variant for Cin % 32 == 0 (all but the first few layers).  A workgroup (4 waves) owns an 8x16
 // output tile of one image and 16*MT output channels.  Per 32-channel chunk of the input it stages
 //   patch [PH*PW pixels][32 ch]   (the tile's receptive field incl. halo, zero outside the image)
@@ -2634,16 +2533,6 @@ int launch_op(Yolo& y, const Yolo::Op& op, hipStream_t st, int B, bool force_dir
                 return AV_OK;
             }
         }
-        // 3x3, cin a multiple of 64 and >= 128, 64 / 80 output channels (the Detect head's first convolutions at P4 / P5): GEMM form
-        // with the tile turned (conv_gemm64_kernel).  AVHOT_CONV_NO_GEMM64: conv_lds_kernel below (tuning aid)
-        if (a.ksz == 3 && a.stride == 1 && a.cin % CG_SC == 0 && a.cin >= 128 && (a.cout == 64 || a.cout == 80) && !a.res && !a.in2 && !op.dec &&
-            a.out && a.kreal == 9 * a.cin && !force_direct && !getenv("AVHOT_CONV_NO_GEMM64")) {
-            const dim3 g64((a.npix + 127) / 128, 1);
-            if (a.cout == 64) hipLaunchKernelGGL(conv_gemm64_kernel<64>, g64, dim3(256), (size_t)2 * (64 + 128) * CG_ROWB, st, a);
-            else hipLaunchKernelGGL(conv_gemm64_kernel<80>, g64, dim3(256), (size_t)2 * (80 + 128) * CG_ROWB, st, a);
-            AV_LAUNCH_CHECK();
-            return AV_OK;
-        }
         if (lds_ok && !force_direct) {
             const int tiles_x = (a.Wo + LT_W - 1) / LT_W, tiles_y = (a.Ho + LT_H - 1) / LT_H;
             const int taps = a.ksz * a.ksz;
@@ -2845,8 +2734,6 @@ int av_yolo_create_ex(av_ctx* ctx, int batch, int in_h, int in_w, const float* w
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 32, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<4, 1, 8, 64, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm64_kernel<80>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<128, 64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<64, 128, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_f32_kernel<80, 128, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
