@@ -70,6 +70,8 @@ def parse():
                     help="N>1: gather with the library's own av_allgather_tracks (RCCL communicator made from a broadcast "
                          "ncclUniqueId) instead of torch.distributed.all_gather_into_tensor")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"], help="config3: detector arithmetic")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1, window 1: time-steps per all-gather (the per-frame tables of k steps in one message)")
     ap.add_argument("--min-seconds", type=float, default=0.2, help="least device time behind every reported figure")
     ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
                     help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
@@ -278,7 +280,10 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     if world > 1 and not a.no_allgather:
         # window 1: every step IS a frame, so the per-frame gather (config 5's wording) is the default there -- and with the
         # one-launch step the wire tables come out of the step kernel itself (no pack launch)
-        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame" or W == 1), native=a.native_allgather)
+        # window 1: the tables of `--gather-every` consecutive time-steps travel in one all-gather (every frame's table is gathered,
+        # k steps at a time: a 13-us step cannot wait for a collective of its own)
+        bucket = max(1, a.gather_every) if (W == 1 and loop.fused_step) else 1
+        xchg = TrackTableExchange(loop, world, rank, per_frame=(a.gather == "per-frame" or W == 1), native=a.native_allgather, bucket=bucket)
     h, s = loop.ctx.handle, loop._s
     cross = xchg is not None or a.taggers     # somebody on the main stream reads the tracker's tables every step
 
@@ -314,6 +319,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
             nat.check(L.av_join(h, s))       # main stream waits for the side stream's tail
         loop.synchronize()
         if xchg is not None:
+            xchg.flush()                      # (a partially filled bucket)
             xchg.synchronize()
 
     for _ in range(max(warmup, 1)):
@@ -422,6 +428,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
            "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_ms": per_rank_ms}
     if xchg is not None:
         out["config"]["allgather_bytes_per_rank_per_step"] = xchg.bytes_per_step
+        out["config"]["allgather_every_steps"] = xchg.bucket
     if stage_kernels is not None:
         out["stage_kernels_replaced"] = stage_kernels
     out["traffic_profiles"] = [pmc_stamp("hot_step_pmc.json")] if loop.fused_step else [pmc_stamp("tracker_pmc.json"), pmc_stamp("planner_pmc.json")]

@@ -126,19 +126,33 @@ class TrackTableExchange:
     code path runs synchronously with the torch statement of the pack kernel.
     per_frame=False: the end-of-window table of every stream; True: all W tables of the window."""
 
-    def __init__(self, loop, world, rank, group=None, per_frame=False, native=None):
+    def __init__(self, loop, world, rank, group=None, per_frame=False, native=None, bucket=1):
         """native=True (or AVHOT_NATIVE_ALLGATHER=1): the gather is the library call av_allgather_tracks on an RCCL
         communicator of its own (made from a ncclUniqueId that rank 0 broadcasts through torch.distributed) instead of
-        torch.distributed.all_gather_into_tensor; GPU tensors only."""
+        torch.distributed.all_gather_into_tensor; GPU tensors only.
+        bucket=k > 1 (window 1 with the one-launch step only): the tables of k consecutive time-steps travel in ONE all-gather --
+        every frame's table is still gathered, k steps at a time.  A 13-us time-step cannot wait for a collective of its own
+        (an 8-rank all-gather of 132 KB costs more than the step); k tables per stream per message amortise it.  The step
+        kernel writes step t's tables into slot t % k of the send buffer; exchange() gathers when the bucket is full (and
+        flush() what a run leaves in a partial one).  latest() then returns hdr [world*S, k], rows [world*S, k, tcap]."""
         self.loop, self.world, self.rank, self.group, self.per_frame = loop, world, rank, group, per_frame
         S, tcap, dev = loop.S, loop.tcap, loop.dev
-        self.n_sel = loop.W if per_frame else 1
+        self.bucket = int(bucket)
+        if self.bucket < 1:
+            raise ValueError("bucket must be >= 1")
+        if self.bucket > 1 and not (bool(getattr(loop, "fused_step", False)) and loop.W == 1):
+            raise ValueError("bucket > 1 needs window 1 with the one-launch step (the step kernel writes the wire tables)")
+        self.n_sel = (loop.W if per_frame else 1) * self.bucket
         self.frame_lo = 0 if per_frame else loop.W - 1
         tb = wire_table_bytes(tcap)
-        self.bytes_per_step = S * self.n_sel * tb
+        self.bytes_per_step = S * (loop.W if per_frame else 1) * tb
+        self.bytes_per_gather = S * self.n_sel * tb
         self.gpu = torch.device(dev).type == "cuda"
-        self.send = [torch.zeros(S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.recv = [torch.zeros(world * S, self.n_sel, tb, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # bucket 1: [S][n_sel][tb] per rank (stream-major, as av_pack_tracks writes it); bucket k: [k][S][tb] (slot-major: the step
+        # kernel writes a whole [S][tb] slot per time-step) -- recv is the ranks' send buffers one after the other either way
+        shape = (S, self.n_sel, tb) if self.bucket == 1 else (self.bucket, S, tb)
+        self.send = [torch.zeros(*shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.recv = [torch.zeros(world * shape[0], *shape[1:], dtype=torch.uint8, device=dev) for _ in range(2)]
         if native is None:
             native = os.environ.get("AVHOT_NATIVE_ALLGATHER", "0") == "1"
         if native and not self.gpu:
@@ -164,7 +178,8 @@ class TrackTableExchange:
             nat.check(L.av_comm_create(loop.ctx.handle, uid, rank, world, C.byref(h)))
             self.nccl = h
         self.done = [None, None]
-        self.k = 0                      # steps exchanged so far; step k uses buffer k & 1
+        self._last = 0                  # receive buffer of the most recent gather
+        self.k = 0                      # steps exchanged so far; step k uses buffer (k // bucket) & 1, slot k % bucket
         # window 1 with the one-launch step (HotLoop.fused_step): the step kernel itself writes the wire tables, straight into
         # the send buffer handed to it by begin_step() -- no pack launch between the step and the gather
         self.prepacked = bool(getattr(loop, "fused_step", False)) and loop.W == 1
@@ -175,16 +190,17 @@ class TrackTableExchange:
         A step enqueued without it is still exchanged correctly -- exchange() then packs the tables itself."""
         if not self.prepacked:
             return
-        b = self.k & 1
-        if self.gpu and self.done[b] is not None:
+        b, slot = (self.k // self.bucket) & 1, self.k % self.bucket
+        if self.gpu and self.done[b] is not None and slot == 0:
             self.loop.stream.wait_event(self.done[b])
-        self.loop.set_wire(self.send[b].view(self.loop.S, -1), stream0=self.rank * self.loop.S, frame0=0)
-        self._handed = b
+        wire = self.send[b].view(self.loop.S, -1) if self.bucket == 1 else self.send[b][slot]
+        self.loop.set_wire(wire, stream0=self.rank * self.loop.S, frame0=0)
+        self._handed = (b, slot)
 
     def exchange(self):
         """Enqueue pack + all-gather of the step just enqueued on loop.stream; returns the receive buffer
         ([world*S, n_sel, table bytes], complete once synchronize() / latest() returns)."""
-        b = self.k & 1
+        b, slot = (self.k // self.bucket) & 1, self.k % self.bucket
         loop = self.loop
         # header.frame: the stream's detector frame count at that frame when the loop keeps the counters (HotLoop does -- the value
         # the one-launch step stamps as well), else the number of frames exchanged before it
@@ -192,42 +208,72 @@ class TrackTableExchange:
         frame0 = 0 if fcount is not None else self.k * loop.W
         # prepacked: the step just enqueued wrote its wire tables into send[b] -- if begin_step() handed it that buffer.  If the
         # caller skipped begin_step() the tables are packed here like in any other mode (never a stale or empty buffer).
-        prepacked = self.prepacked and self._handed == b and getattr(loop, "wire", None) is not None \
-            and loop.wire.data_ptr() == self.send[b].data_ptr()
+        want_ptr = self.send[b].data_ptr() if self.bucket == 1 else self.send[b][slot].data_ptr()
+        prepacked = self.prepacked and self._handed == (b, slot) and getattr(loop, "wire", None) is not None \
+            and loop.wire.data_ptr() == want_ptr
         self._handed = None
         if self.prepacked:
             loop.set_wire(None)                    # a later step without begin_step() must not write into a buffer being gathered
+        if self.bucket > 1:
+            if not prepacked:
+                raise RuntimeError("TrackTableExchange(bucket=%d): call begin_step() before every step" % self.bucket)
+            self.k += 1
+            if slot + 1 < self.bucket:
+                return self.recv[(b + 1) & 1]      # the bucket is still filling: the last complete gather
+            return self._gather(b)
         if not self.gpu:
             if not prepacked:
                 self.send[b].copy_(pack_wire(loop.snap, loop.snap_n, self.frame_lo, self.n_sel, self.rank * loop.S, frame0, fcount))
-            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             self.k += 1
-            return self.recv[b]
+            return self._gather(b)
         if not prepacked:
             if self.done[b] is not None:           # buffer b is still being sent from two steps ago
                 loop.stream.wait_event(self.done[b])
             nat.check(nat.lib().av_pack_tracks(loop.ctx.handle, nat.stream_handle(loop.stream), loop.S, loop.W, loop.tcap,
                                                self.frame_lo, self.n_sel, self.rank * loop.S, frame0, nat.ptr(loop.snap),
                                                nat.ptr(loop.snap_n), nat.ptr(fcount), nat.ptr(self.send[b])))
-        self.ready[b].record(loop.stream)
+        self.k += 1
+        return self._gather(b)
+
+    def _gather(self, b):
+        """Enqueue the all-gather of send buffer b (complete on loop.stream) on the communication stream."""
+        if not self.gpu:
+            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
+            self._last = b
+            return self.recv[b]
+        self.ready[b].record(self.loop.stream)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])
             if self.native:
                 nat.check(nat.lib().av_allgather_tracks(self.loop.ctx.handle, self.nccl, nat.stream_handle(self.comm),
-                                                        nat.ptr(self.send[b]), nat.ptr(self.recv[b]), self.bytes_per_step))
+                                                        nat.ptr(self.send[b]), nat.ptr(self.recv[b]), self.bytes_per_gather))
             else:
                 dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             ev = torch.cuda.Event()
             ev.record(self.comm)
             self.done[b] = ev
-        self.k += 1
+        self._last = b
         return self.recv[b]
+
+    def flush(self):
+        """bucket > 1: gather a partially filled bucket (its unfilled slots still hold the tables of two buckets ago)."""
+        slot = self.k % self.bucket
+        if self.bucket > 1 and slot != 0:
+            b = (self.k // self.bucket) & 1
+            self.k += self.bucket - slot
+            return self._gather(b)
+        return None
 
     def latest(self):
         """Host view (hdr [world*S, n_sel], rows [world*S, n_sel, tcap]) of the most recent gather."""
         self.synchronize()
-        b = (self.k - 1) & 1
-        return unpack_wire(self.recv[b], self.loop.tcap)
+        b = self._last
+        hdr, rows = unpack_wire(self.recv[b], self.loop.tcap)
+        if self.bucket > 1:                    # [world, bucket, S] -> [world * S, bucket]
+            S, k, w = self.loop.S, self.bucket, self.world
+            hdr = np.ascontiguousarray(hdr.reshape(w, k, S).transpose(0, 2, 1)).reshape(w * S, k)
+            rows = np.ascontiguousarray(rows.reshape(w, k, S, -1).transpose(0, 2, 1, 3)).reshape(w * S, k, -1)
+        return hdr, rows
 
     def synchronize(self):
         if self.gpu:

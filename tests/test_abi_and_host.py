@@ -139,6 +139,62 @@ def _gloo_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from multimodal_autonomous_driving_perception_and_planning_amd import distributed as D
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, tcap, K = 3, 64, 3
+        loop = _FakeLoop(S, 1, tcap, fused_step=True)
+        x = D.TrackTableExchange(loop, world, rank, per_frame=True, bucket=K)
+        ok = x.prepacked and x.bucket == K and x.bytes_per_gather == K * S * (16 + 32 * tcap)
+        for k in range(8):                      # two full buckets + a partial one
+            x.begin_step()
+            ok &= loop.wire.data_ptr() == x.send[(k // K) & 1][k % K].data_ptr()
+            loop.step_fused(rank, k)
+            x.exchange()
+            if k % K == K - 1:
+                hdr, rows = x.latest()
+                ok &= hdr.shape == (world * S, K)
+                for g in range(world * S):
+                    for j in range(K):
+                        kk = k - (K - 1) + j
+                        m = 1 + ((g + 3 * kk) % 7)
+                        ok &= int(hdr["n_rows"][g, j]) == m and int(hdr["stream"][g, j]) == g and int(hdr["frame"][g, j]) == kk + 1
+                        ok &= list(rows[g, j]["id"][:m]) == list(100000 * kk + 1000 * g + np.arange(m))
+        x.flush()                               # steps 6, 7 of the third bucket
+        hdr, rows = x.latest()
+        for g in range(world * S):
+            for j, kk in ((0, 6), (1, 7)):
+                m = 1 + ((g + 3 * kk) % 7)
+                ok &= int(hdr["n_rows"][g, j]) == m and int(hdr["frame"][g, j]) == kk + 1
+        try:                                    # a step without begin_step() cannot be bucketed: refused, not silently stale
+            loop.fill(rank, 99)
+            x.exchange()
+            ok = False
+        except RuntimeError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_per_frame_gather_world2_gloo():
+    """TrackTableExchange(bucket=3): the tables of three consecutive time-steps in one all-gather, over two gloo ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
 def test_track_table_allgather_world2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
