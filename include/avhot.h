@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AV_VERSION 101
+#define AV_VERSION 102
 
 enum {
     AV_OK = 0,
@@ -479,6 +479,24 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
                 double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n, int32_t* det2trk,
                 const double* z, double* kf_state, double* vstate, double* plan_state, double* waypoints, double* cost,
                 int32_t* order, void* wire, int stream0, int frame0);
+
+/* Consecutive time-steps OVERLAPPED (still one launch per step, same results bit for bit).  The reference's loop runs frame t + 1
+ * after frame t (demo.py:97-120); what frame t + 1 needs of frame t is the stream's tracker table (tracker role) and its filter
+ * state (Kalman role), not the planner's output.  The caller launches step `seq` (0, 1, 2, ... since the state was reset) on HIP
+ * stream seq % 2 of a pair -- so that step seq + 2 follows step seq in stream order -- and gives steps of different parity
+ * DIFFERENT per-step buffers (det_*, snap, snap_n, det2trk, z, vstate, plan_state, waypoints, cost, order, wire); the persistent
+ * buffers (frame_count, det_status, tracker_state, kf_state) and seq_flags are shared.  On the device a role of step `seq` waits
+ * until seq_flags says its stream's role of step seq - 1 has finished and published its state:
+ *   seq_flags  int32 [AV_STEP_FLAG_INTS(S)], zeroed when the state is reset: [2 s] tracker steps done, [2 s + 1] Kalman steps done
+ *              of stream s, [2 S] fault word -- a workgroup whose wait ran out (AVHOT_STEP_SPIN polls, default 2^22: a predecessor
+ *              that was never launched) sets bit 0 and leaves without running its step; check it after synchronising.
+ * HotLoop(window=1, overlap=2) drives it. */
+#define AV_STEP_FLAG_INTS(n_streams) (2 * (n_streams) + 2)
+int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg, int n_streams, int h,
+                    int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                    double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n, int32_t* det2trk,
+                    const double* z, double* kf_state, double* vstate, double* plan_state, double* waypoints, double* cost,
+                    int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags, int seq);
 
 #ifdef __cplusplus
 }

@@ -33,24 +33,95 @@ struct StepArgs {
     const double* z; double *kf_state, *vstate, *plan_state;
     double *wp, *cost; int32_t* order;
     uint8_t* wire; int stream0, frame0;
+    int* flags; int seq, spin, fence, stage_off;      // consecutive steps overlapped (av_hot_step_seq): see seq_enter
 };
 
 constexpr int STEP_NW = 8;
+
+// ---- consecutive time-steps overlapped --------------------------------------------------------------------------------------------
+// One launch per time-step leaves the chip to ONE kernel of 2 S workgroups whose 13 us are mostly latency (launch, first loads,
+// the Kalman -> arc length -> trajectories chain, the drain of the stores), and step t + 1 only starts when step t has drained.
+// What step t + 1 really needs of step t is less: its tracker role the stream's tracker table, its Kalman role the stream's
+// filter state -- not the planner's 4.5 MB of waypoints.  av_hot_step_seq therefore lets the caller launch steps alternately on
+// TWO HIP streams (step t + 2 follows step t in stream order) and orders step t + 1 behind step t per stream and role on the
+// device: flags[2 s + r] counts the steps whose role r (0 tracker, 1 Kalman) of stream s has finished.  A role of step q waits
+// until its counter reads q and publishes q + 1 when its persistent state is written.
+// Steps land on different XCDs (measured: the predecessor's role had run on another XCD in 99.98 % of 537 600 hand-overs), each
+// with an L2 of its own, so the hand-over has to go through memory:
+//   * an agent-scope ACQUIRE in the consumer would be buffer_inv sc1, which drops the XCD's whole L2 -- that alone takes the
+//     step from 7.9 to 15 us (every table of every workgroup is then re-read from HBM), and an agent-scope RELEASE in the publisher
+//     (buffer_wbl2) waits for the XCD's dirty lines, the planner's waypoints among them.  Neither is used.
+//   * Instead the few bytes that cross a step boundary -- tracker: header + rows (4 160 B) and the frame counter; Kalman: 46 doubles
+//     -- are WRITTEN with device-scope stores (sc1: written through to memory) and READ once, into LDS, with device-scope loads (sc1:
+//     never served from the CU's L1 or from an XCD's possibly stale L2 line); the stage code runs on the LDS copy.  Nothing else a
+//     role reads was written by the previous step.  The publisher's counter store follows a workgroup barrier behind those stores
+//     (s_waitcnt vmcnt(0) in every wave: they are acknowledged, i.e. visible device-wide); the consumer's loads are issued after its
+//     poll has returned the new count.  tests/test_gpu_step.py: 150 unsynchronised steps x 64 streams bit-identical to the serial loop.
+// The per-step outputs (detections, snapshot rows, det2trk, Kalman output, waypoints, costs, order) alternate between two buffer
+// sets on the host side, so steps t and t + 1 never write the same output and the Kalman counter moves on before the planner
+// has run.  At most two steps are in flight (two streams), both fit on the chip together (4 S workgroups of <= 64 KB), and every
+// wait is bounded: after `spin` polls the workgroup sets the fault word flags[2 S] and leaves without running its step
+// (HotLoop.synchronize raises) -- no launch can hang on a lost predecessor.
+__device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) {
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int n = 0; n <= a.spin; ++n) {
+            if (__hip_atomic_load(a.flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.seq) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) atomicOr(a.flags + 2 * a.S, 1);
+        *go = ok;
+    }
+    __syncthreads();                  // (also keeps the compiler from moving any load of the role above the poll)
+    if (!*go) return false;
+    if (a.fence & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // debug: the form the comment above prices
+    return true;
+}
+// by ONE thread, behind a workgroup barrier that follows the role's last (device-scope) store to its persistent state
+__device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
+    if (a.fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(a.flags + slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// n8 8-byte words of the predecessor's record into LDS, by the first `nthreads` threads of the workgroup (device-scope loads)
+__device__ __forceinline__ void fetch_coherent(const void* src, void* dst_lds, int n8, int nthreads) {
+    const unsigned long long* g = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* l = reinterpret_cast<unsigned long long*>(dst_lds);
+    for (int i = threadIdx.x; i < n8; i += nthreads)
+        l[i] = __hip_atomic_load(const_cast<unsigned long long*>(g) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // PW: waves of a planner workgroup (the tracker role always runs on STEP_NW = 8; with PW = 16 its workgroups' other eight waves leave
 // at once).  The 3 C = 21 trajectories of a start state are dealt to the waves whole: eight waves take three rounds, sixteen two.
 template <int PW>
 __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int go, fc_stage;
+    __shared__ __attribute__((aligned(16))) double kf_stage[AV_KF_STATE_DOUBLES + 2];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.S) {
         if (PW > STEP_NW && tid >= STEP_NW * 64) return;
         const int s = blockIdx.x;
-        if (tid == 0)
+        const unsigned char* table = nullptr;
+        if (a.flags) {
+            if (!seq_enter(a, 2 * s, &go)) return;
+            unsigned char* stage = smem + a.stage_off;
+            int fc0 = 0;
+            if (tid == 0) fc0 = __hip_atomic_load(a.frame_count + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (in flight with the table)
+            fetch_coherent(a.trk_state + (size_t)s * state_bytes(a.tcap, a.tcfg.trajectory_length), stage,
+                           (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, STEP_NW * 64);
+            if (tid == 0) {
+                fc_stage = fc0;
+                simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
+                                   a.det_status ? a.det_status + s : nullptr);
+                __hip_atomic_store(a.frame_count + s, fc_stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            table = stage;
+        } else if (tid == 0) {
             simdet_frame<true>(s, s, 0, a.h, a.w, a.dcap, a.frame_count, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf, a.det_status);
+        }
         __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0))
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, a.det_n, a.det_box, a.det_cls, a.det_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
-                                        a.det2trk, 1, s, smem);
+                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, table);
         if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
             __syncthreads();          // the snapshot rows the bookkeeper wave wrote
             // frame = frame0 + the stream's detector frame count after this step: read from memory, so that a captured graph
@@ -59,24 +130,52 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
                 wire_put(a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES), tid, a.snap_n[s], a.tcap,
                          a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + a.frame_count[s]);
         }
+        if (a.flags) {
+            __syncthreads();          // every wave's stores (table, rings, counters, outputs) are complete
+            if (tid == 0) seq_leave(a, 2 * s);
+        }
     } else {
         const int s = blockIdx.x - a.S;
-        if (tid < 64) {
+        if (a.flags) {
+            if (!seq_enter(a, 2 * s + 1, &go)) return;
+            if (tid < 64) {
+                // the filter runs on a copy of the stream's record (fetched past the caches) and the record is rewritten from it
+                double* rec = a.kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
+                if (tid < AV_KF_STATE_DOUBLES)
+                    kf_stage[tid] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(rec) + tid, __ATOMIC_RELAXED,
+                                                                                      __HIP_MEMORY_SCOPE_AGENT));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                const double* z = a.z + (size_t)s * 4;
+                double *vs = a.vstate + (size_t)s * AV_VSTATE_DOUBLES, *ps = a.plan_state + (size_t)s * 4;
+                const bool separable = kf_axis_body(a.kcfg, 1, z, nullptr, kf_stage, vs, ps, 0, tid);
+                if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, 0, 1, z, nullptr, kf_stage, vs, ps);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                if (tid < AV_KF_STATE_DOUBLES)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec) + tid, (unsigned long long)__double_as_longlong(kf_stage[tid]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (tid < 64) {
             const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid);
             if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);   // (LDS form: kf_dense.inc)
         }
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
+        if (a.flags && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
         plan_block<1, PW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
     }
 }
 
 }  // namespace
 
-extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
                            int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
                            double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
                            int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
-                           double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0) {
+                           double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags,
+                           int seq) {
     AV_REQUIRE(ctx && tcfg && kcfg && frame_count && det_n && det_box && det_cls && det_conf && tracker_state && z && kf_state &&
                    vstate && plan_state && cost && order,
                AV_EINVAL, "av_hot_step: null argument");
@@ -98,12 +197,22 @@ extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
     a.z = z, a.kf_state = kf_state, a.vstate = vstate, a.plan_state = plan_state;
     a.wp = waypoints, a.cost = cost, a.order = order;
     a.wire = (uint8_t*)wire, a.stream0 = stream0, a.frame0 = frame0;
+    a.flags = seq_flags, a.seq = seq;
+    const char* spe = seq_flags ? getenv("AVHOT_STEP_SPIN") : nullptr;
+    a.spin = spe ? atoi(spe) : (1 << 22);
+    const char* fe = seq_flags ? getenv("AVHOT_STEP_FENCE") : nullptr;
+    a.fence = fe ? atoi(fe) : 0;     // (debug: 1 = full agent-scope acquire in every role, the form the comment above prices)
     // dynamic LDS: the larger of the tracker's (av_tracker_update's layout for one staged frame, eight replicas) and the planner's
     const int fc = 1;
     const size_t chunk_bytes = (size_t)((fc + 3) & ~3) * 4 + (size_t)fc * dcap * 16 + (((size_t)fc * dcap + 1) & ~size_t(1)) * 4 +
                                (size_t)fc * dcap * 16 + 16;
     const size_t rep_bytes = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
-    const size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
+    size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
+    if (seq_flags) {                  // + the copy of the stream's header and rows the overlapped step runs on
+        lds_t = (lds_t + 15) & ~size_t(15);
+        a.stage_off = (int)lds_t;
+        lds_t += HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row);
+    }
     const char* pwe = getenv("AVHOT_STEP_PW");
     const int pw = pwe && atoi(pwe) == 8 ? 8 : 16;
     const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, pw) * 8;
@@ -119,4 +228,26 @@ extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
     else hipLaunchKernelGGL(hot_step_kernel<8>, dim3(2 * n_streams), dim3(8 * 64), lds, as_stream(stream), a);
     AV_LAUNCH_CHECK();
     return AV_OK;
+}
+
+extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+                           int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                           double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
+                           int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
+                           double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0) {
+    return hot_step_launch(ctx, stream, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
+                           tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
+                           frame0, nullptr, 0);
+}
+
+extern "C" int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+                               int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                               double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
+                               int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
+                               double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0,
+                               int32_t* seq_flags, int seq) {
+    AV_REQUIRE(seq_flags && seq >= 0, AV_EINVAL, "av_hot_step_seq: needs the sequence flags (AV_STEP_FLAG_INTS(n_streams) zeroed int32) and seq >= 0");
+    return hot_step_launch(ctx, stream, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
+                           tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
+                           frame0, seq_flags, seq);
 }

@@ -102,7 +102,9 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
                                int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
-                               const unsigned long long wave_map = 0xFEDCBA9876543210ull) {
+                               const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr) {
+    // init_src: where the stream's header and rows are read from at entry instead of its state record (the overlapped time-step of
+    // step.hip hands over a copy it fetched with device-scope loads); everything is written to the state record as always
     constexpr bool REPL = REP > 1;
     static_assert(!(REPL && MULTIWAVE), "replica waves hold the whole table: tcap must be 64");
     static_assert(REP == 1 || REP == 8, "the exchange buffers are laid out for 8 columns");
@@ -154,10 +156,12 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
     av_track_row* rows = reinterpret_cast<av_track_row*>(st + HDR_INTS * 4);
     double* hist = reinterpret_cast<double*>(st + HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row));
 
-    int T = hdr[0], next_id = hdr[1], frame_count = hdr[2], status = hdr[3];
+    const int* hdr_in = init_src ? reinterpret_cast<const int*>(init_src) : hdr;
+    const av_track_row* rows_in = init_src ? reinterpret_cast<const av_track_row*>(init_src + HDR_INTS * 4) : rows;
+    int T = hdr_in[0], next_id = hdr_in[1], frame_count = hdr_in[2], status = hdr_in[3];
     Row r{};
     if (row < T) {
-        const av_track_row g = rows[row];
+        const av_track_row g = rows_in[row];
         r.id = g.id, r.x1 = g.x1, r.y1 = g.y1, r.x2 = g.x2, r.y2 = g.y2, r.cls = g.cls;
         r.age = g.age, r.hits = g.hits, r.misses = g.misses, r.slot = g.slot, r.hlen = g.hist_len;
         r.hpos = g.hist_len % L;
@@ -671,9 +675,25 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
         g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
         g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
         g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;
-        rows[row] = g;
+        if (init_src) {               // overlapped steps: the successor may run on another XCD -- device-scope (write-through) stores
+            unsigned long long w[sizeof(av_track_row) / 8];
+            __builtin_memcpy(w, &g, sizeof(g));
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(rows + row);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(av_track_row) / 8); ++i) __hip_atomic_store(d + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            rows[row] = g;
+        }
     }
-    if (row == 0) hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
+    if (row == 0) {
+        if (init_src) {
+            const int hv[4] = {T, next_id, frame_count, status};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(hdr + i, hv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
+        }
+    }
 }
 
 template <bool MULTIWAVE, int DREG, int REP, bool TIMED = false, int PIPE = 0>

@@ -21,10 +21,15 @@ from . import _native as nat
 class HotLoop:
     def __init__(self, n_streams=1, window=1, h=720, w=1280, tcap=64, dcap=8, device=0,
                  tracker_kw=None, kf_kw=None, planner_kw=None, keep_waypoints=True, keep_snapshots=True,
-                 ctx=None, fused_step=None):
+                 ctx=None, fused_step=None, overlap=1):
         """fused_step: with window 1, run a time-step as ONE launch (av_hot_step: role-split workgroups running the stage
         kernels' own device code, same results bit for bit) instead of the four stage launches.  None = whenever the
-        configuration allows it (window 1, tcap 64, dcap 7..8, iou_threshold > 0)."""
+        configuration allows it (window 1, tcap 64, dcap 7..8, iou_threshold > 0).
+        overlap=2 (fused step only): consecutive steps are launched alternately on two HIP streams and ordered per stream and
+        role on the device (av_hot_step_seq), so step t + 1 starts while step t's planner is still writing.  The per-step
+        buffers (det_*, snap, snap_n, det2trk, z, vstate, plan_state, wp, cost, order) then exist twice; the attributes always
+        name the set of the step enqueued LAST (for `z`: the set the NEXT step will read), and that set is next written by
+        the step after the next one.  Same results as overlap=1 bit for bit."""
         if not torch.cuda.is_available():
             raise RuntimeError("HotLoop needs a HIP device; this package has no CPU path")
         self.S, self.W, self.h, self.w, self.tcap, self.dcap = n_streams, window, h, w, tcap, dcap
@@ -78,16 +83,37 @@ class HotLoop:
         self.fused_step = can_fuse if fused_step is None else bool(fused_step)
         self.wire = None                  # set_wire(): the fused step also writes every stream's table in wire format
         self._wire_ids = (0, 0)
+        self.overlap = int(overlap)
+        if self.overlap not in (1, 2):
+            raise ValueError("overlap is 1 or 2")
+        if self.overlap == 2:
+            if not self.fused_step:
+                raise ValueError("overlap=2 needs the fused step (window 1, tcap 64, dcap 7..8, iou_threshold > 0)")
+            names = [k for k in self._PER_STEP if getattr(self, k) is not None]
+            self._sets = [{k: getattr(self, k) for k in names}, {k: torch.zeros_like(getattr(self, k)) for k in names}]
+            self._pstreams = [self.stream, torch.cuda.Stream(device=d)]
+            self.seq_flags = torch.zeros(2 * S + 2, dtype=i32, device=d)
+            self._seq = 0
         self.reset()
+
+    _PER_STEP = ("det_n", "det_box", "det_cls", "det_conf", "snap", "snap_n", "det2trk", "z", "vstate", "plan_state", "wp",
+                 "cost", "order")
 
     # ------------------------------------------------------------------------------------------
     @property
     def _s(self):
         return C.c_void_p(self.stream.cuda_stream)
 
+    def _serial_only(self, what):
+        if self.overlap != 1:
+            raise RuntimeError("%s is not available with overlap=2 (only the one-launch step is ordered across the two streams)" % what)
+
     def reset(self, frame_offsets=None):
         """Resets every stream (tracker.reset(), state_estimator.reset(), detector.reset())."""
         h, L = self.ctx.handle, self.L
+        if self.overlap == 2:
+            for st in self._pstreams:
+                st.synchronize()
         nat.check(L.av_tracker_reset(h, self._s, self.S, self.tcap, self.tcfg.trajectory_length, nat.ptr(self.trk_state)))
         nat.check(L.av_kf_reset(h, self._s, self.S, nat.ptr(self.kf_state)))
         with torch.cuda.stream(self.stream):
@@ -95,22 +121,36 @@ class HotLoop:
                 self.frame_count.zero_()
             else:
                 self.frame_count.copy_(torch.as_tensor(np.asarray(frame_offsets, np.int32)), non_blocking=False)
+            if self.overlap == 2:
+                self.seq_flags.zero_()
+        if self.overlap == 2:
+            self._seq = 0
+            self.__dict__.update(self._sets[0])
         self.stream.synchronize()
 
     def load_measurements(self, z):
         """z: float64 [S, W, 4] ego measurements for the next window (host array)."""
+        if self.overlap == 2:                 # the next step's set, on the next step's stream
+            k = self._seq & 1
+            self.z = self._sets[k]["z"]
+            with torch.cuda.stream(self._pstreams[k]):
+                self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
+            self._pstreams[k].synchronize()
+            return
         with torch.cuda.stream(self.stream):
             self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
         self.stream.synchronize()
 
     # ---- individual stages (enqueue only) --------------------------------------------------------
     def enqueue_detect(self, stream=None):
+        self._serial_only("enqueue_detect")
         nat.check(self.L.av_simdet_generate(self.ctx.handle, stream or self._s, self.S, self.W, self.h, self.w,
                                             self.dcap, nat.ptr(self.frame_count), nat.ptr(self.det_n),
                                             nat.ptr(self.det_box), nat.ptr(self.det_cls), nat.ptr(self.det_conf),
                                             nat.ptr(self.det_status)))
 
     def enqueue_track(self, stream=None):
+        self._serial_only("enqueue_track")
         nat.check(self.L.av_tracker_update(self.ctx.handle, stream or self._s, C.byref(self.tcfg), self.S, self.W,
                                            self.dcap, nat.ptr(self.det_n), nat.ptr(self.det_box),
                                            nat.ptr(self.det_cls), nat.ptr(self.det_conf), self.tcap,
@@ -118,6 +158,7 @@ class HotLoop:
                                            nat.ptr(self.det2trk)))
 
     def enqueue_kf(self, stream=None):
+        self._serial_only("enqueue_kf")
         nat.check(self.L.av_kf_step(self.ctx.handle, stream or self._s, C.byref(self.kcfg), self.S, self.W,
                                     nat.ptr(self.z), None, nat.ptr(self.kf_state), nat.ptr(self.vstate),
                                     nat.ptr(self.plan_state)))
@@ -126,6 +167,7 @@ class HotLoop:
         """Maneuver tags of every frame of the window from the Kalman output (ManeuverDetector.detect,
         maneuver_detector.py:105-262); call after enqueue_kf on the same stream.  Results: self.maneuver
         (uint8 view of av_maneuver_row [S][W])."""
+        self._serial_only("enqueue_maneuver")
         if not hasattr(self, "mv_state"):
             self.mv_state = torch.zeros(self.S, nat.MANEUVER_STATE_DOUBLES, dtype=torch.float64, device=self.dev)
             self.maneuver = torch.zeros(self.S, self.W, nat.MANEUVER_ROW_BYTES, dtype=torch.uint8, device=self.dev)
@@ -136,6 +178,7 @@ class HotLoop:
         """Interaction tags of every frame of the window from the tracker's snapshot tables and the Kalman output
         (InteractionDetector.detect, interaction_detector.py:132-222); call where both are complete (after the
         join).  Results: self.inter_rows (av_interaction_row [S][W][tcap]), self.inter_summary ([S][W])."""
+        self._serial_only("enqueue_interactions")
         from .perception.detector import ObjectDetector
         from .tagging.interaction_detector import interaction_cfg
         if self.tcap != 64 or self.snap is None:
@@ -156,6 +199,7 @@ class HotLoop:
         painted on the device from the tables the step left in HBM; call where tracker, Kalman and planner outputs are
         complete (after the join).  Results: self.bev (uint8 [S, 600, 600, 3]).  The trails come from the tracker's
         history rings, i.e. they are those of the window's last frame (the default)."""
+        self._serial_only("enqueue_bev")
         from .visualization.bev_renderer import BEVRenderer
         if not (self.keep_waypoints and self.keep_snapshots):
             raise RuntimeError("enqueue_bev needs keep_waypoints=True and keep_snapshots=True")
@@ -182,6 +226,7 @@ class HotLoop:
                                         nat.ptr(self._bev_prims), self._bev_cap, nat.ptr(self._bev_n), None, 0))
 
     def enqueue_plan(self, stream=None):
+        self._serial_only("enqueue_plan")
         nat.check(self.L.av_planner_plan(self.ctx.handle, stream or self._s, self.S * self.W,
                                          nat.ptr(self.plan_state), None, 0, None, 0, nat.ptr(self.wp),
                                          nat.ptr(self.cost), nat.ptr(self.order)))
@@ -196,6 +241,8 @@ class HotLoop:
 
     def enqueue_step_fused(self, stream=None):
         """Window 1: detect + track + Kalman + plan of one frame of every stream as ONE launch."""
+        if self.overlap == 2:
+            return self._enqueue_step_seq(stream)
         nat.check(self.L.av_hot_step(self.ctx.handle, stream or self._s, C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h,
                                      self.w, self.dcap, self.tcap, nat.ptr(self.frame_count), nat.ptr(self.det_n),
                                      nat.ptr(self.det_box), nat.ptr(self.det_cls), nat.ptr(self.det_conf),
@@ -203,6 +250,27 @@ class HotLoop:
                                      nat.ptr(self.det2trk), nat.ptr(self.z), nat.ptr(self.kf_state), nat.ptr(self.vstate),
                                      nat.ptr(self.plan_state), nat.ptr(self.wp), nat.ptr(self.cost), nat.ptr(self.order),
                                      nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1]))
+
+    def _enqueue_step_seq(self, stream=None):
+        """overlap=2: step number self._seq on stream seq % 2 with buffer set seq % 2, ordered behind step seq - 1 per stream and
+        role by the sequence flags (av_hot_step_seq)."""
+        if stream is not None:
+            raise RuntimeError("overlap=2 launches on the loop's own pair of streams")
+        k = self._seq & 1
+        b = self._sets[k]
+        self.__dict__.update(b)              # the attributes name the set of the step enqueued last
+        nat.check(self.L.av_hot_step_seq(self.ctx.handle, C.c_void_p(self._pstreams[k].cuda_stream), C.byref(self.tcfg), C.byref(self.kcfg),
+                                         self.S, self.h, self.w, self.dcap, self.tcap, nat.ptr(self.frame_count), nat.ptr(b["det_n"]),
+                                         nat.ptr(b["det_box"]), nat.ptr(b["det_cls"]), nat.ptr(b["det_conf"]),
+                                         nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(b.get("snap")), nat.ptr(b.get("snap_n")),
+                                         nat.ptr(b["det2trk"]), nat.ptr(b["z"]), nat.ptr(self.kf_state), nat.ptr(b["vstate"]),
+                                         nat.ptr(b["plan_state"]), nat.ptr(b.get("wp")), nat.ptr(b["cost"]), nat.ptr(b["order"]),
+                                         nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq))
+        self._seq += 1
+
+    def step_stream(self):
+        """The torch stream the step enqueued last runs on (overlap=2 alternates between two)."""
+        return self._pstreams[(self._seq - 1) & 1] if self.overlap == 2 and self._seq else self.stream
 
     def enqueue_step(self):
         """One window of the whole loop: fork{detect; track} || {kf; plan}; join.  Detections only feed the
@@ -219,8 +287,10 @@ class HotLoop:
         nat.check(L.av_join(h, s))
 
     def capture(self):
-        """Capture enqueue_step() into a hipGraph (replayed by step(graph=True)).  The fused step bakes the wire buffer's
+        """Capture enqueue_step() into a hipGraph (replayed by step(graph=True)).  (overlap=2: not available -- a graph would
+        replay one step number.)  The fused step bakes the wire buffer's
         address into its kernel arguments, so graphs are kept per wire buffer (the exchange alternates between two)."""
+        self._serial_only("capture()")
         gid = C.c_int(-1)
         nat.check(self.L.av_graph_begin(self.ctx.handle, self._s))
         try:
@@ -243,22 +313,29 @@ class HotLoop:
         else:
             self.enqueue_step()
         if sync:
-            self.stream.synchronize()
+            self.synchronize()
 
-    def synchronize(self):
+    def synchronize(self, check=True):
+        if self.overlap == 2:
+            for st in self._pstreams:
+                st.synchronize()
+            if check and int(self.seq_flags[2 * self.S].item()) != 0:
+                raise RuntimeError("HotLoop(overlap=2): a step waited in vain for its predecessor (sequence flags: fault word set); "
+                                   "the state is no longer that of a serial run -- reset()")
+            return
         self.stream.synchronize()
 
     # ---- host views of the last window -------------------------------------------------------------
     def snapshots(self):
         """-> (rows structured array [S,W,tcap], n [S,W]) for the last window."""
-        self.stream.synchronize()
+        self.synchronize()
         raw = self.snap.cpu().numpy()
         rows = raw.view(np.dtype(nat.TRACK_ROW_FIELDS)).reshape(self.S, self.W, self.tcap)
         return rows, self.snap_n.cpu().numpy()
 
     def tracker_tables(self):
         """Persistent per-stream state: (hdr int32[S,16], rows [S,tcap], hist float64[S,tcap,L,4])."""
-        self.stream.synchronize()
+        self.synchronize()
         raw = self.trk_state.cpu().numpy()
         L = self.tcfg.trajectory_length
         hdr = raw[:, :nat.TRACKER_HDR_BYTES].copy().view(np.int32)
@@ -268,7 +345,7 @@ class HotLoop:
         return hdr, rows, hist
 
     def results(self):
-        self.stream.synchronize()
+        self.synchronize()
         out = dict(det_n=self.det_n.cpu().numpy(), det_box=self.det_box.cpu().numpy(),
                    det_cls=self.det_cls.cpu().numpy(), det_conf=self.det_conf.cpu().numpy(),
                    det2trk=self.det2trk.cpu().numpy(), vstate=self.vstate.cpu().numpy(),

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) >= 29
     for n in names:
         assert hasattr(lib, n), "libavhot.so lacks %s declared in include/avhot.h" % n
-    assert lib.av_version() == 101
+    assert lib.av_version() == 102
     assert {s[0] for s in nat._SIGS + nat._OPTIONAL_SIGS} >= set(names), "ctypes binding missing for a declared symbol"
 
 

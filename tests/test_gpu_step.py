@@ -110,3 +110,87 @@ def test_fused_step_refuses_shapes_it_is_not_built_for(torch):
     with pytest.raises(ValueError):
         HotLoop(n_streams=2, window=1, tcap=128, fused_step=True)
     assert not HotLoop(n_streams=2, window=1, tcap=128).fused_step        # falls back to the stage launches by itself
+
+
+def _valid_rows(o):
+    """Snapshot rows past a frame's live count are not written by the step (they keep whatever an earlier step left, and the two
+    buffer sets of overlap=2 have different histories): compare the live rows only."""
+    snap = o["snap"].copy()
+    S, W = o["snap_n"].shape
+    snap = snap.reshape(S, W, 64, -1)
+    for s in range(S):
+        for f in range(W):
+            snap[s, f, o["snap_n"][s, f]:] = 0
+    o["snap"] = snap
+    return o
+
+
+def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
+    """HotLoop(overlap=2): consecutive steps on two HIP streams, ordered per stream and role by the device-side sequence flags
+    (av_hot_step_seq).  (a) enqueued back to back without any host synchronisation -- the case the flags exist for -- every
+    step's wire table (one buffer per step) and the state after the last step equal the serial loop's; (b) synchronised step by
+    step, every per-step output equals the serial loop's."""
+    from multimodal_autonomous_driving_perception_and_planning_amd import _native as nat
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    from oracle.harness_ref import run_stream
+    S, steps = 64, 150
+    offs = [17 * s for s in range(S)]
+    z = np.stack([run_stream(steps, frame_offset=offs[s], ego_seed=s)["z"] for s in range(S)])       # [S, steps, 4]
+    wb = int(nat.lib().av_wire_table_bytes(64))
+    serial = HotLoop(n_streams=S, window=1)
+    over = HotLoop(n_streams=S, window=1, overlap=2)
+    assert serial.fused_step and over.overlap == 2
+    # (a) constant measurements (the step reads z from its buffer set; both sets are loaded once), no host synchronisation
+    wires = {}
+    for name, lp in (("serial", serial), ("over", over)):
+        lp.reset(frame_offsets=offs)
+        w = torch.zeros(steps, S, wb, dtype=torch.uint8, device=lp.dev)
+        if lp.overlap == 2:
+            for k in range(2):
+                lp._sets[k]["z"].copy_(torch.as_tensor(z[:, :1]))
+            torch.cuda.synchronize()
+        else:
+            lp.load_measurements(z[:, :1])
+        for t in range(steps):
+            lp.set_wire(w[t], stream0=40, frame0=1000)
+            lp.enqueue_step()
+        lp.synchronize()
+        wires[name] = w.cpu().numpy()
+    for t in range(steps):
+        assert np.array_equal(wires["serial"][t], wires["over"][t]), ("wire table of step", t)
+    _same(_valid_rows(_outputs(serial)), _valid_rows(_outputs(over)), "after %d unsynchronised steps" % steps)
+    fl = over.seq_flags.cpu().numpy()
+    assert fl[:2 * S].tolist() == [steps] * (2 * S) and fl[2 * S] == 0
+    # (b) fresh measurements every step, every output of every step
+    for lp in (serial, over):
+        lp.set_wire(None)
+        lp.reset(frame_offsets=offs)
+    for t in range(60):
+        for lp in (serial, over):
+            lp.load_measurements(z[:, t:t + 1])
+            lp.enqueue_step()
+        _same(_valid_rows(_outputs(serial)), _valid_rows(_outputs(over)), "step %d" % t)
+    # the stage calls are not ordered across the two streams: refused, not raced
+    with pytest.raises(RuntimeError, match="overlap=2"):
+        over.enqueue_track()
+    with pytest.raises(RuntimeError, match="overlap=2"):
+        over.step(graph=True)
+
+
+def test_overlapped_step_without_its_predecessor_faults_instead_of_hanging(torch, monkeypatch):
+    from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+    monkeypatch.setenv("AVHOT_STEP_SPIN", "2000")
+    lp = HotLoop(n_streams=4, window=1, overlap=2)
+    lp.reset()
+    lp.enqueue_step()
+    lp.synchronize()
+    lp._seq = 5                              # steps 1..4 were never launched: step 5 waits for a counter that stays at 1
+    lp.enqueue_step()
+    with pytest.raises(RuntimeError, match="waited in vain"):
+        lp.synchronize()
+    assert lp.frame_count.cpu().numpy().tolist() == [1] * 4          # the faulted step did not run
+    lp.reset()                               # clears the flags and the fault word
+    lp.enqueue_step()
+    lp.enqueue_step()
+    lp.synchronize()
+    assert lp.frame_count.cpu().numpy().tolist() == [2] * 4
