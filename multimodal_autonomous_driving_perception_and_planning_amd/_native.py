@@ -113,6 +113,8 @@ _SIGS = [
     ("av_planner_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("av_planner_plan", C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
     ("av_hot_step", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 17 + [vp, C.c_int, C.c_int]),
+    ("av_hot_steps_seq", C.c_int, [vp, vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 8 +
+     [C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("av_hot_step_seq", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 17 +
      [vp, C.c_int, C.c_int, vp, C.c_int]),
     ("av_planner_generate", C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
@@ -212,6 +214,12 @@ def register(sigs):
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
+
+
+class StepSet(C.Structure):
+    """av_step_set: the per-step buffers of one parity (av_hot_steps_seq)."""
+    _fields_ = [(k, C.c_void_p) for k in ("det_n", "det_box", "det_cls", "det_conf", "snap", "snap_n", "det2trk", "z", "vstate",
+                                          "plan_state", "waypoints", "cost", "order")]
 
 
 def check(rc):

@@ -44,7 +44,7 @@ constexpr int STEP_NW = 8;
 // What step t + 1 really needs of step t is less: its tracker role the stream's tracker table, its Kalman role the stream's
 // filter state -- not the planner's 4.5 MB of waypoints.  av_hot_step_seq therefore lets the caller launch steps alternately on
 // TWO HIP streams (step t + 2 follows step t in stream order) and orders step t + 1 behind step t per stream and role on the
-// device: flags[2 s + r] counts the steps whose role r (0 tracker, 1 Kalman) of stream s has finished.  A role of step q waits
+// device: a counter per stream and role (0 tracker, 1 Kalman) holds the number of steps whose role has finished.  A role of step q waits
 // until its counter reads q and publishes q + 1 when its persistent state is written.
 // Steps land on different XCDs (measured: the predecessor's role had run on another XCD in 99.98 % of 537 600 hand-overs), each
 // with an L2 of its own, so the hand-over has to go through memory:
@@ -60,16 +60,21 @@ constexpr int STEP_NW = 8;
 // The per-step outputs (detections, snapshot rows, det2trk, Kalman output, waypoints, costs, order) alternate between two buffer
 // sets on the host side, so steps t and t + 1 never write the same output and the Kalman counter moves on before the planner
 // has run.  At most two steps are in flight (two streams), both fit on the chip together (4 S workgroups of <= 64 KB), and every
-// wait is bounded: after `spin` polls the workgroup sets the fault word flags[2 S] and leaves without running its step
+// wait is bounded: after `spin` polls the workgroup sets the fault word (bit 0) and leaves without running its step
 // (HotLoop.synchronize raises) -- no launch can hang on a lost predecessor.
+// seq_flags layout (AV_STEP_FLAG_INTS): one 128-byte line per counter -- 2 S pollers hammer them -- then the fault word's line, then
+// the streams' detector frame counts at reset (the count before step q is base + q: the detections do not have to wait)
+__device__ __host__ inline int flag_fault(int S) { return 64 * S; }
+__device__ __host__ inline int flag_base(int S) { return 64 * S + 32; }
+
 __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) {
     if (threadIdx.x == 0) {
         int ok = 0;
         for (int n = 0; n <= a.spin; ++n) {
-            if (__hip_atomic_load(a.flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.seq) { ok = 1; break; }
+            if (__hip_atomic_load(a.flags + 32 * slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.seq) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) atomicOr(a.flags + 2 * a.S, 1);
+        if (!ok) atomicOr(a.flags + flag_fault(a.S), 1);
         *go = ok;
     }
     __syncthreads();                  // (also keeps the compiler from moving any load of the role above the poll)
@@ -80,7 +85,7 @@ __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) 
 // by ONE thread, behind a workgroup barrier that follows the role's last (device-scope) store to its persistent state
 __device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
     if (a.fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(a.flags + slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.flags + 32 * slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // n8 8-byte words of the predecessor's record into LDS, by the first `nthreads` threads of the workgroup (device-scope loads)
 __device__ __forceinline__ void fetch_coherent(const void* src, void* dst_lds, int n8, int nthreads) {
@@ -103,6 +108,14 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         const int s = blockIdx.x;
         const unsigned char* table = nullptr;
         if (a.flags) {
+            // the detections first: the detector's count before step q is its count at reset + q, no need to wait for step q - 1
+            // (tid 0 checks that against the counter the predecessor left: fault bit 1)
+            const int fc_before = a.flags[flag_base(a.S) + s] + a.seq;
+            if (tid == 0) {
+                fc_stage = fc_before;
+                simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
+                                   a.det_status ? a.det_status + s : nullptr);
+            }
             if (!seq_enter(a, 2 * s, &go)) return;
             unsigned char* stage = smem + a.stage_off;
             int fc0 = 0;
@@ -110,9 +123,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             fetch_coherent(a.trk_state + (size_t)s * state_bytes(a.tcap, a.tcfg.trajectory_length), stage,
                            (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, STEP_NW * 64);
             if (tid == 0) {
-                fc_stage = fc0;
-                simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
-                                   a.det_status ? a.det_status + s : nullptr);
+                if (fc0 != fc_before) atomicOr(a.flags + flag_fault(a.S), 2);
                 __hip_atomic_store(a.frame_count + s, fc_stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             table = stage;
@@ -128,7 +139,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             // (fixed kernel arguments) stamps every replay with its own index
             if (tid < a.tcap)
                 wire_put(a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES), tid, a.snap_n[s], a.tcap,
-                         a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + a.frame_count[s]);
+                         a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + (a.flags ? fc_stage : a.frame_count[s]));
         }
         if (a.flags) {
             __syncthreads();          // every wave's stores (table, rings, counters, outputs) are complete
@@ -170,12 +181,13 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
 
 }  // namespace
 
-static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+// validates one step's arguments and fills its kernel arguments (lds: dynamic LDS bytes, pw: waves per workgroup)
+static int hot_step_args(av_ctx* ctx, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
                            int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
                            double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
                            int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
                            double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags,
-                           int seq) {
+                           int seq, StepArgs& a, size_t& lds_out, int& pw_out) {
     AV_REQUIRE(ctx && tcfg && kcfg && frame_count && det_n && det_box && det_cls && det_conf && tracker_state && z && kf_state &&
                    vstate && plan_state && cost && order,
                AV_EINVAL, "av_hot_step: null argument");
@@ -187,7 +199,7 @@ static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
     AV_REQUIRE(tcap == 64 && dcap >= 7 && dcap <= 8 && tcfg->iou_threshold > 0.0 && tcfg->trajectory_length >= 1, AV_EINVAL,
                "av_hot_step: needs tcap 64, dcap 7..8 and iou_threshold > 0 (use the stage calls otherwise)");
     AV_REQUIRE(h > 0 && w > 121, AV_EINVAL, "av_hot_step: frame %dx%d too small", w, h);
-    StepArgs a{};
+    a = StepArgs{};
     a.S = n_streams, a.h = h, a.w = w, a.dcap = dcap, a.tcap = tcap;
     a.tcfg = *tcfg, a.kcfg = *kcfg;
     fill_params(ctx, a.pp);
@@ -224,10 +236,30 @@ static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
     }();
     AV_REQUIRE(lds + lds_static <= 64 * 1024, AV_EINVAL, "av_hot_step: configuration needs %zu B of dynamic + %zu B of static LDS (limit 65536)",
                lds, lds_static);
-    if (pw == 16) hipLaunchKernelGGL(hot_step_kernel<16>, dim3(2 * n_streams), dim3(16 * 64), lds, as_stream(stream), a);
-    else hipLaunchKernelGGL(hot_step_kernel<8>, dim3(2 * n_streams), dim3(8 * 64), lds, as_stream(stream), a);
+    lds_out = lds, pw_out = pw;
+    return AV_OK;
+}
+
+static int hot_step_go(const StepArgs& a, size_t lds, int pw, av_stream_t stream) {
+    if (pw == 16) hipLaunchKernelGGL(hot_step_kernel<16>, dim3(2 * a.S), dim3(16 * 64), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(hot_step_kernel<8>, dim3(2 * a.S), dim3(8 * 64), lds, as_stream(stream), a);
     AV_LAUNCH_CHECK();
     return AV_OK;
+}
+
+static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
+                           int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
+                           double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
+                           int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
+                           double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags,
+                           int seq) {
+    StepArgs a;
+    size_t lds;
+    int pw;
+    const int rc = hot_step_args(ctx, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
+                                 tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
+                                 frame0, seq_flags, seq, a, lds, pw);
+    return rc != AV_OK ? rc : hot_step_go(a, lds, pw, stream);
 }
 
 extern "C" int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg, int n_streams, int h,
@@ -250,4 +282,33 @@ extern "C" int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker
     return hot_step_launch(ctx, stream, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
                            tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
                            frame0, seq_flags, seq);
+}
+
+extern "C" int av_hot_steps_seq(av_ctx* ctx, av_stream_t stream_even, av_stream_t stream_odd, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg,
+                                int n_streams, int h, int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_status,
+                                void* tracker_state, double* kf_state, const av_step_set* set_even, const av_step_set* set_odd,
+                                const double* z_steps, void* wire_steps, int stream0, int frame0, int32_t* seq_flags, int seq0, int n_steps) {
+    AV_REQUIRE(seq_flags && seq0 >= 0 && n_steps > 0 && set_even && set_odd, AV_EINVAL, "av_hot_steps_seq: bad argument");
+    AV_REQUIRE(stream_even != stream_odd, AV_EINVAL, "av_hot_steps_seq: the two parities need two different HIP streams");
+    StepArgs par[2];
+    size_t lds = 0;
+    int pw = 16;
+    for (int k = 0; k < 2; ++k) {
+        const av_step_set& b = k ? *set_odd : *set_even;
+        const int rc = hot_step_args(ctx, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, b.det_n, b.det_box, b.det_cls, b.det_conf, det_status,
+                                     tracker_state, b.snap, b.snap_n, b.det2trk, z_steps ? z_steps : b.z, kf_state, b.vstate, b.plan_state,
+                                     b.waypoints, b.cost, b.order, wire_steps, stream0, frame0, seq_flags, seq0, par[k], lds, pw);
+        if (rc != AV_OK) return rc;
+    }
+    const size_t zb = (size_t)n_streams * 4, wb = (size_t)n_streams * (AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES);
+    for (int i = 0; i < n_steps; ++i) {
+        const int q = seq0 + i, k = q & 1;
+        StepArgs& a = par[k];
+        a.seq = q;
+        if (z_steps) a.z = z_steps + (size_t)i * zb;
+        if (wire_steps) a.wire = (uint8_t*)wire_steps + (size_t)i * wb;
+        const int rc = hot_step_go(a, lds, pw, k ? stream_odd : stream_even);
+        if (rc != AV_OK) return rc;
+    }
+    return AV_OK;
 }

@@ -185,6 +185,28 @@ class TrackTableExchange:
         self.prepacked = bool(getattr(loop, "fused_step", False)) and loop.W == 1
         self._handed = None             # the send buffer begin_step() handed to the loop for the step being enqueued
 
+    def _loop_streams(self):
+        """The torch stream(s) the loop's steps run on (HotLoop(overlap=2) alternates between two)."""
+        return list(getattr(self.loop, "_pstreams", None) or [self.loop.stream])
+
+    def step_bucket(self, z_steps=None):
+        """HotLoop(overlap=2) only: ONE bucket -- `bucket` consecutive time-steps enqueued by one library call
+        (HotLoop.enqueue_steps), every step's wire tables written by the step kernels straight into the send buffer -- and its
+        all-gather.  Replaces `bucket` rounds of begin_step() / enqueue_step() / exchange()."""
+        loop = self.loop
+        if getattr(loop, "overlap", 1) != 2 or not self.prepacked:
+            raise RuntimeError("step_bucket needs HotLoop(window=1, overlap=2)")
+        if self.k % self.bucket:
+            raise RuntimeError("step_bucket: a bucket is being filled step by step (%d of %d)" % (self.k % self.bucket, self.bucket))
+        b = (self.k // self.bucket) & 1
+        if self.gpu and self.done[b] is not None:          # the gather that last read this send buffer
+            for st in self._loop_streams():
+                st.wait_event(self.done[b])
+        loop.set_wire(None, stream0=self.rank * loop.S, frame0=0)
+        loop.enqueue_steps(self.bucket, z_steps=z_steps, wire_steps=self.send[b])
+        self.k += self.bucket
+        return self._gather(b)
+
     def begin_step(self):
         """Call BEFORE enqueuing step k when `prepacked`: hands send buffer k & 1 to the loop (after the gather that last read it).
         A step enqueued without it is still exchanged correctly -- exchange() then packs the tables itself."""
@@ -192,7 +214,8 @@ class TrackTableExchange:
             return
         b, slot = (self.k // self.bucket) & 1, self.k % self.bucket
         if self.gpu and self.done[b] is not None and slot == 0:
-            self.loop.stream.wait_event(self.done[b])
+            for st in self._loop_streams():
+                st.wait_event(self.done[b])
         wire = self.send[b].view(self.loop.S, -1) if self.bucket == 1 else self.send[b][slot]
         self.loop.set_wire(wire, stream0=self.rank * self.loop.S, frame0=0)
         self._handed = (b, slot)
@@ -241,9 +264,14 @@ class TrackTableExchange:
             dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self.group)
             self._last = b
             return self.recv[b]
-        self.ready[b].record(self.loop.stream)
+        streams = self._loop_streams()
+        self.ready[b].record(streams[0])
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[b])
+            for st in streams[1:]:                 # (overlap=2: the bucket's steps ran on both streams)
+                ev2 = torch.cuda.Event()
+                ev2.record(st)
+                self.comm.wait_event(ev2)
             if self.native:
                 nat.check(nat.lib().av_allgather_tracks(self.loop.ctx.handle, self.nccl, nat.stream_handle(self.comm),
                                                         nat.ptr(self.send[b]), nat.ptr(self.recv[b]), self.bytes_per_gather))

@@ -92,8 +92,9 @@ class HotLoop:
             names = [k for k in self._PER_STEP if getattr(self, k) is not None]
             self._sets = [{k: getattr(self, k) for k in names}, {k: torch.zeros_like(getattr(self, k)) for k in names}]
             self._pstreams = [self.stream, torch.cuda.Stream(device=d)]
-            self.seq_flags = torch.zeros(2 * S + 2, dtype=i32, device=d)
+            self.seq_flags = torch.zeros(65 * S + 32, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
             self._seq = 0
+            self._csets = None
         self.reset()
 
     _PER_STEP = ("det_n", "det_box", "det_cls", "det_conf", "snap", "snap_n", "det2trk", "z", "vstate", "plan_state", "wp",
@@ -123,19 +124,22 @@ class HotLoop:
                 self.frame_count.copy_(torch.as_tensor(np.asarray(frame_offsets, np.int32)), non_blocking=False)
             if self.overlap == 2:
                 self.seq_flags.zero_()
+                self.seq_flags[64 * self.S + 32:].copy_(self.frame_count)
         if self.overlap == 2:
             self._seq = 0
             self.__dict__.update(self._sets[0])
         self.stream.synchronize()
 
-    def load_measurements(self, z):
-        """z: float64 [S, W, 4] ego measurements for the next window (host array)."""
+    def load_measurements(self, z, all_sets=False):
+        """z: float64 [S, W, 4] ego measurements for the next window (host array).  overlap=2: for the next STEP (its buffer
+        set); all_sets=True: for every step from now on (both sets)."""
         if self.overlap == 2:                 # the next step's set, on the next step's stream
-            k = self._seq & 1
-            self.z = self._sets[k]["z"]
-            with torch.cuda.stream(self._pstreams[k]):
-                self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
-            self._pstreams[k].synchronize()
+            zt = torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4)
+            for k in ((self._seq & 1, (self._seq + 1) & 1) if all_sets else (self._seq & 1,)):
+                with torch.cuda.stream(self._pstreams[k]):
+                    self._sets[k]["z"].copy_(zt)
+                self._pstreams[k].synchronize()
+            self.z = self._sets[self._seq & 1]["z"]
             return
         with torch.cuda.stream(self.stream):
             self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
@@ -268,6 +272,34 @@ class HotLoop:
                                          nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq))
         self._seq += 1
 
+    def enqueue_steps(self, n_steps, z_steps=None, wire_steps=None):
+        """overlap=2: n_steps consecutive steps enqueued by one library call (av_hot_steps_seq: the launch loop in C).
+        z_steps: None (every step reads its buffer set's z) or a float64 device tensor [n_steps, S, 4], the measurements of each
+        step; wire_steps: None or a uint8 device tensor [n_steps, S, av_wire_table_bytes(tcap)] that receives every step's
+        wire tables (set_wire's stream0 / frame0 apply)."""
+        if self.overlap != 2:
+            raise RuntimeError("enqueue_steps needs overlap=2")
+        if n_steps <= 0:
+            return
+        if self._csets is None:
+            def cset(b):
+                m = {"wp": "waypoints"}
+                return nat.StepSet(**{m.get(k, k): (b[k].data_ptr() if b.get(k) is not None else None) for k in self._PER_STEP})
+            self._csets = [cset(b) for b in self._sets]
+        if z_steps is not None and (z_steps.dtype != torch.float64 or z_steps.numel() != n_steps * self.S * 4 or not z_steps.is_contiguous()):
+            raise ValueError("z_steps: contiguous float64 [n_steps, S, 4]")
+        if wire_steps is not None:
+            wb = int(self.L.av_wire_table_bytes(self.tcap))
+            if not (self.keep_snapshots and wire_steps.dtype == torch.uint8 and wire_steps.numel() == n_steps * self.S * wb and wire_steps.is_contiguous()):
+                raise ValueError("wire_steps: contiguous uint8 [n_steps, S, %d] (and keep_snapshots=True)" % wb)
+        nat.check(self.L.av_hot_steps_seq(self.ctx.handle, C.c_void_p(self._pstreams[0].cuda_stream), C.c_void_p(self._pstreams[1].cuda_stream),
+                                          C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h, self.w, self.dcap, self.tcap,
+                                          nat.ptr(self.frame_count), nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(self.kf_state),
+                                          C.byref(self._csets[0]), C.byref(self._csets[1]), nat.ptr(z_steps), nat.ptr(wire_steps),
+                                          self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq, int(n_steps)))
+        self._seq += int(n_steps)
+        self.__dict__.update(self._sets[(self._seq - 1) & 1])
+
     def step_stream(self):
         """The torch stream the step enqueued last runs on (overlap=2 alternates between two)."""
         return self._pstreams[(self._seq - 1) & 1] if self.overlap == 2 and self._seq else self.stream
@@ -319,7 +351,7 @@ class HotLoop:
         if self.overlap == 2:
             for st in self._pstreams:
                 st.synchronize()
-            if check and int(self.seq_flags[2 * self.S].item()) != 0:
+            if check and int(self.seq_flags[64 * self.S].item()) != 0:
                 raise RuntimeError("HotLoop(overlap=2): a step waited in vain for its predecessor (sequence flags: fault word set); "
                                    "the state is no longer that of a serial run -- reset()")
             return

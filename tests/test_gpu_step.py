@@ -145,12 +145,7 @@ def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
     for name, lp in (("serial", serial), ("over", over)):
         lp.reset(frame_offsets=offs)
         w = torch.zeros(steps, S, wb, dtype=torch.uint8, device=lp.dev)
-        if lp.overlap == 2:
-            for k in range(2):
-                lp._sets[k]["z"].copy_(torch.as_tensor(z[:, :1]))
-            torch.cuda.synchronize()
-        else:
-            lp.load_measurements(z[:, :1])
+        lp.load_measurements(z[:, :1], **({"all_sets": True} if lp.overlap == 2 else {}))
         for t in range(steps):
             lp.set_wire(w[t], stream0=40, frame0=1000)
             lp.enqueue_step()
@@ -160,7 +155,7 @@ def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
         assert np.array_equal(wires["serial"][t], wires["over"][t]), ("wire table of step", t)
     _same(_valid_rows(_outputs(serial)), _valid_rows(_outputs(over)), "after %d unsynchronised steps" % steps)
     fl = over.seq_flags.cpu().numpy()
-    assert fl[:2 * S].tolist() == [steps] * (2 * S) and fl[2 * S] == 0
+    assert fl[0:64 * S:32].tolist() == [steps] * (2 * S) and fl[64 * S] == 0
     # (b) fresh measurements every step, every output of every step
     for lp in (serial, over):
         lp.set_wire(None)
@@ -170,6 +165,21 @@ def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
             lp.load_measurements(z[:, t:t + 1])
             lp.enqueue_step()
         _same(_valid_rows(_outputs(serial)), _valid_rows(_outputs(over)), "step %d" % t)
+    # (c) the launch loop in C (av_hot_steps_seq): fresh measurements for every step from one device tensor, every step's wire tables
+    for lp in (serial, over):
+        lp.reset(frame_offsets=offs)
+    ws = torch.zeros(steps, S, wb, dtype=torch.uint8, device=serial.dev)
+    for t in range(steps):
+        serial.load_measurements(z[:, t:t + 1])
+        serial.set_wire(ws[t], stream0=7, frame0=50)
+        serial.enqueue_step()
+    wo = torch.zeros_like(ws)
+    zs = torch.as_tensor(np.ascontiguousarray(z.transpose(1, 0, 2))).to(over.dev)          # [steps, S, 4]
+    over.set_wire(None, stream0=7, frame0=50)
+    over.enqueue_steps(100, z_steps=zs[:100], wire_steps=wo[:100])
+    over.enqueue_steps(steps - 100, z_steps=zs[100:], wire_steps=wo[100:])                  # an odd/even split: parity carries over
+    _same(_valid_rows(_outputs(serial)), _valid_rows(_outputs(over)), "after the C launch loop")
+    assert torch.equal(ws, wo)
     # the stage calls are not ordered across the two streams: refused, not raced
     with pytest.raises(RuntimeError, match="overlap=2"):
         over.enqueue_track()

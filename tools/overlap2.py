@@ -26,12 +26,7 @@ for K in (() if os.environ.get("SKIPK") else (1, 2, 3, 4)):
 
 for ov in (1, 2):
     lp = HotLoop(n_streams=S, window=1, overlap=ov)
-    if ov == 2:
-        for k in range(2):
-            lp._sets[k]["z"].copy_(torch.as_tensor(z))
-        torch.cuda.synchronize()
-    else:
-        lp.load_measurements(z)
+    lp.load_measurements(z, **({"all_sets": True} if ov == 2 else {}))
     for _ in range(200): lp.enqueue_step()
     lp.synchronize()
     N = 4000
@@ -41,3 +36,14 @@ for ov in (1, 2):
     lp.synchronize()
     t2 = time.perf_counter()
     print("HotLoop(overlap=%d): host enqueue %.2f us/step, until the device is done %.2f us/step" % (ov, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
+
+lp = HotLoop(n_streams=S, window=1, overlap=2)
+lp.load_measurements(z, all_sets=True)
+lp.enqueue_steps(200); lp.synchronize()
+for N in (4000, 20000):
+    t0 = time.perf_counter()
+    lp.enqueue_steps(N)
+    t1 = time.perf_counter()
+    lp.synchronize()
+    t2 = time.perf_counter()
+    print("HotLoop(overlap=2).enqueue_steps(%d): host enqueue %.2f us/step, until the device is done %.2f us/step" % (N, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
