@@ -72,14 +72,15 @@ def parse():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"], help="config3: detector arithmetic")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1, window 1: time-steps per all-gather (the per-frame tables of k steps in one message)")
-    ap.add_argument("--overlap", type=int, default=2, choices=[1, 2],
-                    help="window 1: 2 = consecutive time-steps overlapped (HotLoop(overlap=2): still one launch per step, ordered per "
-                         "stream and role by device-side counters); 1 = each launch after the previous one has drained")
+    ap.add_argument("--overlap", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="window 1: D > 1 = up to D consecutive time-steps in flight (HotLoop(overlap=D): still one launch per step, "
+                         "ordered per stream and role by device-side counters); 1 = each launch after the previous one has drained")
     ap.add_argument("--min-seconds", type=float, default=0.2, help="least device time behind every reported figure")
     ap.add_argument("--gather", default="window-end", choices=["window-end", "per-frame"],
                     help="N>1: all-gather the end-of-window table (cheap) or every frame's table of the window")
     ap.add_argument("--no-defer", action="store_true", help="config3: whole lane chain inside its own step")
-    ap.add_argument("--no-tune", action="store_true", help="config3: keep the first main stream (no PerceptionLoop.tune_streams())")
+    ap.add_argument("--no-tune", action="store_true", help="keep the loops' first streams (no tune_streams(): which hardware queues a "
+                                                           "process's streams get depends on its stream history)")
     ap.add_argument("--taggers", action="store_true",
                     help="also run the maneuver and interaction taggers (SURVEY 8f-3) in every step")
     ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
@@ -275,13 +276,14 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     ov = (a.overlap if overlap is None else overlap) if (W == 1 and not graph and not a.taggers) else 1
     loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True, overlap=ov)
     ov = loop.overlap
+    tuned = loop.tune_streams() if (ov > 1 and not a.no_tune) else None      # (which hardware queues the D streams got decides how the launches overlap)
     L = nat.lib()
     g0 = rank * S                                      # global stream ids of this rank
     loop.reset(frame_offsets=[(g0 + s) * 17 for s in range(S)])   # offset s*17
     # synthetic ego measurements: one seeded sequence per stream, re-used every window (input data only)
     zlen = max(W, 64)
     z = np.stack([np.asarray(generate_ego_motion(zlen, seed=g0 + s), np.float64)[:W] for s in range(S)])
-    if ov == 2:
+    if ov > 1:
         loop.load_measurements(z, all_sets=True)
     else:
         loop.load_measurements(z)
@@ -297,10 +299,10 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     cross = xchg is not None or a.taggers     # somebody on the main stream reads the tracker's tables every step
     # overlapped loop: the launch loop of `unit` consecutive time-steps is one library call (av_hot_steps_seq; a Python call per
     # launch costs 8 us, the device needs 7.4) -- with a gather, one bucket of `--gather-every` steps and its all-gather
-    unit = (xchg.bucket if xchg is not None else max(1, a.gather_every)) if ov == 2 else 1
+    unit = (xchg.bucket if xchg is not None else max(1, a.gather_every)) if ov > 1 else 1
 
     def one_step():
-        if ov == 2:
+        if ov > 1:
             if xchg is not None:
                 xchg.step_bucket()
             else:
@@ -369,16 +371,16 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     if int(np.abs(hdr[:, 3]).max()) != 0:
         raise RuntimeError("tracker table overflow (hdr[3] != 0): tcap %d too small for this run" % loop.tcap)
     t_inflight = None
-    if ov == 2:
-        # a launch's own duration while two are in flight (HIP events around every launch on the stream it runs on, the loop
+    if ov > 1:
+        # a launch's own duration while `ov` are in flight (HIP events around every launch on the stream it runs on, the loop
         # stepping launch by launch): what rocprofv3 --kernel-trace reports for hot_step_kernel on this command.  It contains the
-        # waits for the predecessor; the step rate above is two of these at a time.
+        # waits for the predecessor; the step rate above is `ov` of these at a time.
         for _ in range(64):
             loop.enqueue_step()
         loop.synchronize()
         ev = Events(L, nat, 256)
         for e in ev.ev:
-            st = C.c_void_p(loop._pstreams[loop._seq & 1].cuda_stream)
+            st = C.c_void_p(loop._pstreams[loop._seq % ov].cuda_stream)
             nat.check(L.av_event_record(e[0], st))
             loop.enqueue_step()
             nat.check(L.av_event_record(e[1], st))
@@ -440,15 +442,15 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                "achieved": hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(hbm((TRACKER_BYTES + KF_BYTES + SIMDET_BYTES) * F + pb, t_fused) / HBM_PEAK_GBS, 5),
                "traffic": pmc_traffic("hot_step_pmc.json", "hbm_bytes_per_stream_step", F)}]
-    if ov == 2:
+    if ov > 1:
         k0 = ks[0]
         k0["avg_ms_alone"] = k0["avg_ms"]
         k0["avg_ms"] = t_inflight
         k0["achieved"] = hbm(k0["bytes_per_launch"], t_inflight)
         k0["frac"] = round(k0["achieved"] / HBM_PEAK_GBS, 5)
-        k0["launches_in_flight"] = 2
+        k0["launches_in_flight"] = ov
         k0["launch_interval_ms"] = round(el / nsteps * 1e3, 6)
-        k0["why"] += ("; consecutive launches overlap (two in flight, ordered per stream and role by device-side counters): a launch "
+        k0["why"] += ("; consecutive launches overlap (%d in flight, ordered per stream and role by device-side counters): a launch " % ov +
                       "takes avg_ms including its waits, one completes every launch_interval_ms")
     dom = max(ks, key=lambda k: k["avg_ms"])
     roof = {k: dom[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "launches_in_flight",
@@ -472,11 +474,12 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "%s: %d stream(s)/GPU x %d-frame window per step, 1280x720, simulated detection + IoU "
                                   "tracker + 6-state KF + 21-candidate planner%s" % (name, S, W, ", one hipGraph replay per step" if graph else
-                                                              ((", one launch per step, consecutive steps overlapped" if ov == 2 else ", one launch per step") if W == 1 else "")),
+                                                              ((", one launch per step, up to %d consecutive steps in flight" % ov if ov > 1 else ", one launch per step") if W == 1 else "")),
                       "streams_per_gpu": S, "window": W, "graph": bool(graph), "taggers": bool(a.taggers),
                       "allgather_track_tables": (("per-frame" if xchg.per_frame else "window-end") if xchg is not None else False),
                       "allgather_impl": (("av_allgather_tracks (RCCL)" if xchg.native else "torch.distributed") if xchg is not None else None),
                       "fused_step": bool(loop.fused_step), "overlapped_steps": ov, "steps_per_library_call": unit,
+                      "stream_sets_tried_us_per_step": tuned,
                       "parallelism": "stream-sharded x%d" % world},
            "roofline": roof, "kernels": finish_kernel_list(ks),
            "step": {"critical_branch": "side (detect+track)" if side > main else "main (kf+plan)",
@@ -790,7 +793,7 @@ def main():
     if world == 1 and not a.no_also and a.workload == "config4":
         also = {}
         if (a.window or 1) == 1:
-            if head["config"].get("overlapped_steps") == 2:
+            if head["config"].get("overlapped_steps", 1) > 1:
                 # the same steps with every launch waiting for the previous one to drain (round 3's form of the headline)
                 also["config4_serial_launches"] = with_cpu(hot("config4", a.streams or 64, 1, False, 20, 5, overlap=1), cpu_hot)
             also["config4_window256"] = with_cpu(hot("config4, throughput form: 256-frame windows, one hipGraph replay per window",

@@ -483,8 +483,8 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
 /* Consecutive time-steps OVERLAPPED (still one launch per step, same results bit for bit).  The reference's loop runs frame t + 1
  * after frame t (demo.py:97-120); what frame t + 1 needs of frame t is the stream's tracker table (tracker role) and its filter
  * state (Kalman role), not the planner's output.  The caller launches step `seq` (0, 1, 2, ... since the state was reset) on HIP
- * stream seq % 2 of a pair -- so that step seq + 2 follows step seq in stream order -- and gives steps of different parity
- * DIFFERENT per-step buffers (det_*, snap, snap_n, det2trk, z, vstate, plan_state, waypoints, cost, order, wire); the persistent
+ * stream seq % D of D = 2 .. 4 streams -- so that step seq + D follows step seq in stream order -- and gives the D steps that may
+ * be in flight DIFFERENT per-step buffers (det_*, snap, snap_n, det2trk, z, vstate, plan_state, waypoints, cost, order, wire); the persistent
  * buffers (frame_count, det_status, tracker_state, kf_state) and seq_flags are shared.  On the device a role of step `seq` waits
  * until seq_flags says its stream's role of step seq - 1 has finished and published its state:
  *   seq_flags  int32 [AV_STEP_FLAG_INTS(S)], set up when the state is reset: [32 (2 s + r)] = 0, the steps done by role r (0 tracker,
@@ -492,19 +492,23 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
  *              (AVHOT_STEP_SPIN polls, default 2^22: a predecessor that was never launched) and it left without running its step,
  *              bit 1: frame_count[s] was not base + seq; check it after synchronising; [64 S + 32 + s] = frame_count[s] at the
  *              reset (the detections of step seq are made for frame count base + seq + 1 without waiting for step seq - 1).
- * HotLoop(window=1, overlap=2) drives it. */
+ * `depth` = D: up to D launches may be in flight, each possibly waiting for the one before it, so all of them must be RESIDENT
+ * together: the call picks sixteen or eight waves per workgroup accordingly and returns AV_EINVAL when D launches of 2 S workgroups
+ * cannot fit (64 streams: D <= 2 with sixteen waves, <= 4 with eight).  HotLoop(window=1, overlap=D) drives it. */
 #define AV_STEP_FLAG_INTS(n_streams) (65 * (n_streams) + 32)
 int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg, int n_streams, int h,
                     int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
                     double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n, int32_t* det2trk,
                     const double* z, double* kf_state, double* vstate, double* plan_state, double* waypoints, double* cost,
-                    int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags, int seq);
+                    int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags, int seq, int depth);
 
 /* n_steps consecutive overlapped steps (seq0, seq0 + 1, ...) enqueued by ONE call: the launch loop of av_hot_step_seq in C (a Python
- * caller spends 8 us per launch, the device 6-7).  Step q runs on stream_even / stream_odd and writes set_even / set_odd by the parity
- * of q, so after the call the two sets hold the outputs of the last two steps.
+ * caller spends 8 us per launch, the device 6-7), with `depth` (2 .. AV_STEP_MAX_DEPTH) steps in flight: step q runs on
+ * streams[q % depth] and writes sets[q % depth], so after the call the sets hold the outputs of the last `depth` steps.  All launches
+ * in flight have to fit on the device together (depth * 2 S workgroups, two per CU): AV_EINVAL otherwise.
  *   z_steps     NULL (every step reads its set's z), or [n_steps][S][4]: the measurements of step seq0 + i at z_steps + i * S * 4
  *   wire_steps  NULL, or [n_steps][S][av_wire_table_bytes(tcap)]: every step's wire tables (the per-frame all-gather's payload) */
+#define AV_STEP_MAX_DEPTH 4
 typedef struct av_step_set {
     int32_t *det_n, *det_box, *det_cls;
     double* det_conf;
@@ -514,10 +518,10 @@ typedef struct av_step_set {
     double *vstate, *plan_state, *waypoints, *cost;
     int32_t* order;
 } av_step_set;
-int av_hot_steps_seq(av_ctx* ctx, av_stream_t stream_even, av_stream_t stream_odd, const av_tracker_cfg* tracker_cfg,
-                     const av_kf_cfg* kf_cfg, int n_streams, int h, int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_status,
-                     void* tracker_state, double* kf_state, const av_step_set* set_even, const av_step_set* set_odd,
-                     const double* z_steps, void* wire_steps, int stream0, int frame0, int32_t* seq_flags, int seq0, int n_steps);
+int av_hot_steps_seq(av_ctx* ctx, int depth, const av_stream_t* streams, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg,
+                     int n_streams, int h, int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_status, void* tracker_state,
+                     double* kf_state, const av_step_set* sets, const double* z_steps, void* wire_steps, int stream0, int frame0,
+                     int32_t* seq_flags, int seq0, int n_steps);
 
 #ifdef __cplusplus
 }

@@ -113,10 +113,10 @@ _SIGS = [
     ("av_planner_dims", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("av_planner_plan", C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]),
     ("av_hot_step", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 17 + [vp, C.c_int, C.c_int]),
-    ("av_hot_steps_seq", C.c_int, [vp, vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 8 +
+    ("av_hot_steps_seq", C.c_int, [vp, C.c_int, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 7 +
      [C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("av_hot_step_seq", C.c_int, [vp, vp, C.POINTER(TrackerCfg), C.POINTER(KfCfg)] + [C.c_int] * 5 + [vp] * 17 +
-     [vp, C.c_int, C.c_int, vp, C.c_int]),
+     [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("av_planner_generate", C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
     ("av_planner_evaluate", C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]),
     ("av_lane_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -12,6 +12,7 @@ struct PlannerTables;
 
 struct av_ctx {
     int device = -1;
+    int n_cus = 256;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // planner

@@ -53,6 +53,7 @@ int av_ctx_create(int device, av_ctx** out) {
     av_ctx* c = new (std::nothrow) av_ctx();
     AV_REQUIRE(c, AV_ENOMEM, "av_ctx_create: out of host memory");
     c->device = device;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     AV_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     AV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     AV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));

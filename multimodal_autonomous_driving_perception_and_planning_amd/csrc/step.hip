@@ -87,12 +87,13 @@ __device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
     if (a.fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_store(a.flags + 32 * slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// n8 8-byte words of the predecessor's record into LDS, by the first `nthreads` threads of the workgroup (device-scope loads)
-__device__ __forceinline__ void fetch_coherent(const void* src, void* dst_lds, int n8, int nthreads) {
-    const unsigned long long* g = reinterpret_cast<const unsigned long long*>(src);
+// n8 8-byte words of a stream's record into LDS, by the first `nthreads` threads of the workgroup.  coherent: device-scope loads (the
+// record was written by the previous step, possibly on another XCD).
+__device__ __forceinline__ void fetch_record(const void* src, void* dst_lds, int n8, int nthreads, bool coherent) {
+    unsigned long long* g = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(src));
     unsigned long long* l = reinterpret_cast<unsigned long long*>(dst_lds);
     for (int i = threadIdx.x; i < n8; i += nthreads)
-        l[i] = __hip_atomic_load(const_cast<unsigned long long*>(g) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l[i] = coherent ? __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[i];
 }
 
 // PW: waves of a planner workgroup (the tracker role always runs on STEP_NW = 8; with PW = 16 its workgroups' other eight waves leave
@@ -103,78 +104,76 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     __shared__ int go, fc_stage;
     __shared__ __attribute__((aligned(16))) double kf_stage[AV_KF_STATE_DOUBLES + 2];
     const int tid = threadIdx.x;
+    const bool seq = a.flags != nullptr;          // consecutive steps overlapped: wait for / publish to the neighbouring launches
+    // Both roles run on an LDS copy of the stream's record (tracker: header + rows; Kalman: the filter's 46 doubles), fetched by the
+    // whole workgroup at once -- with device-scope loads and stores when the neighbouring steps are separate launches in flight.
     if ((int)blockIdx.x < a.S) {
         if (PW > STEP_NW && tid >= STEP_NW * 64) return;
         const int s = blockIdx.x;
-        const unsigned char* table = nullptr;
-        if (a.flags) {
-            // the detections first: the detector's count before step q is its count at reset + q, no need to wait for step q - 1
-            // (tid 0 checks that against the counter the predecessor left: fault bit 1)
-            const int fc_before = a.flags[flag_base(a.S) + s] + a.seq;
-            if (tid == 0) {
-                fc_stage = fc_before;
-                simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
-                                   a.det_status ? a.det_status + s : nullptr);
-            }
-            if (!seq_enter(a, 2 * s, &go)) return;
-            unsigned char* stage = smem + a.stage_off;
-            int fc0 = 0;
-            if (tid == 0) fc0 = __hip_atomic_load(a.frame_count + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (in flight with the table)
-            fetch_coherent(a.trk_state + (size_t)s * state_bytes(a.tcap, a.tcfg.trajectory_length), stage,
-                           (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, STEP_NW * 64);
-            if (tid == 0) {
+        // the detections first: overlapped, the detector's count before step q is its count at reset + q -- no need to wait for step
+        // q - 1 (tid 0 checks that against the counter the predecessor left: fault bit 1)
+        int fc_before = 0;
+        if (tid == 0) {
+            fc_before = seq ? a.flags[flag_base(a.S) + s] + a.seq : a.frame_count[s];
+            fc_stage = fc_before;
+            simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
+                               a.det_status ? a.det_status + s : nullptr);
+        }
+        if (seq && !seq_enter(a, 2 * s, &go)) return;
+        unsigned char* stage = smem + a.stage_off;
+        int fc0 = 0;
+        if (seq && tid == 0) fc0 = __hip_atomic_load(a.frame_count + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (in flight with the table)
+        fetch_record(a.trk_state + (size_t)s * state_bytes(a.tcap, a.tcfg.trajectory_length), stage,
+                     (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, STEP_NW * 64, seq);
+        if (tid == 0) {
+            if (seq) {
                 if (fc0 != fc_before) atomicOr(a.flags + flag_fault(a.S), 2);
                 __hip_atomic_store(a.frame_count + s, fc_stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                a.frame_count[s] = fc_stage;
             }
-            table = stage;
-        } else if (tid == 0) {
-            simdet_frame<true>(s, s, 0, a.h, a.w, a.dcap, a.frame_count, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf, a.det_status);
         }
-        __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0))
+        __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0)); the table copy is in LDS
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, a.det_n, a.det_box, a.det_cls, a.det_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
-                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, table);
+                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq);
         if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
             __syncthreads();          // the snapshot rows the bookkeeper wave wrote
-            // frame = frame0 + the stream's detector frame count after this step: read from memory, so that a captured graph
-            // (fixed kernel arguments) stamps every replay with its own index
+            // frame = frame0 + the stream's detector frame count after this step (a captured graph -- fixed kernel arguments -- stamps
+            // every replay with its own index)
             if (tid < a.tcap)
                 wire_put(a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES), tid, a.snap_n[s], a.tcap,
-                         a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + (a.flags ? fc_stage : a.frame_count[s]));
+                         a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + fc_stage);
         }
-        if (a.flags) {
+        if (seq) {
             __syncthreads();          // every wave's stores (table, rings, counters, outputs) are complete
             if (tid == 0) seq_leave(a, 2 * s);
         }
     } else {
         const int s = blockIdx.x - a.S;
-        if (a.flags) {
-            if (!seq_enter(a, 2 * s + 1, &go)) return;
-            if (tid < 64) {
-                // the filter runs on a copy of the stream's record (fetched past the caches) and the record is rewritten from it
-                double* rec = a.kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
-                if (tid < AV_KF_STATE_DOUBLES)
-                    kf_stage[tid] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(rec) + tid, __ATOMIC_RELAXED,
-                                                                                      __HIP_MEMORY_SCOPE_AGENT));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                const double* z = a.z + (size_t)s * 4;
-                double *vs = a.vstate + (size_t)s * AV_VSTATE_DOUBLES, *ps = a.plan_state + (size_t)s * 4;
-                const bool separable = kf_axis_body(a.kcfg, 1, z, nullptr, kf_stage, vs, ps, 0, tid);
-                if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, 0, 1, z, nullptr, kf_stage, vs, ps);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                if (tid < AV_KF_STATE_DOUBLES)
+        if (seq && !seq_enter(a, 2 * s + 1, &go)) return;
+        if (tid < 64) {
+            double* rec = a.kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
+            fetch_record(rec, kf_stage, AV_KF_STATE_DOUBLES, 64, seq);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const double* z = a.z + (size_t)s * 4;
+            double *vs = a.vstate + (size_t)s * AV_VSTATE_DOUBLES, *ps = a.plan_state + (size_t)s * 4;
+            const bool separable = kf_axis_body(a.kcfg, 1, z, nullptr, kf_stage, vs, ps, 0, tid);
+            if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, 0, 1, z, nullptr, kf_stage, vs, ps);   // (LDS form: kf_dense.inc)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (tid < AV_KF_STATE_DOUBLES) {
+                if (seq)
                     __hip_atomic_store(reinterpret_cast<unsigned long long*>(rec) + tid, (unsigned long long)__double_as_longlong(kf_stage[tid]),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    rec[tid] = kf_stage[tid];
             }
-        } else if (tid < 64) {
-            const bool separable = kf_axis_body(a.kcfg, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state, s, tid);
-            if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, s, 1, a.z, nullptr, a.kf_state, a.vstate, a.plan_state);   // (LDS form: kf_dense.inc)
         }
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
-        if (a.flags && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
+        if (seq && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
         plan_block<1, PW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
     }
 }
@@ -187,7 +186,7 @@ static int hot_step_args(av_ctx* ctx, const av_tracker_cfg* tcfg, const av_kf_cf
                            double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
                            int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
                            double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags,
-                           int seq, StepArgs& a, size_t& lds_out, int& pw_out) {
+                           int seq, StepArgs& a, size_t& lds_out, int& pw_out, int depth = 1) {
     AV_REQUIRE(ctx && tcfg && kcfg && frame_count && det_n && det_box && det_cls && det_conf && tracker_state && z && kf_state &&
                    vstate && plan_state && cost && order,
                AV_EINVAL, "av_hot_step: null argument");
@@ -220,15 +219,27 @@ static int hot_step_args(av_ctx* ctx, const av_tracker_cfg* tcfg, const av_kf_cf
                                (size_t)fc * dcap * 16 + 16;
     const size_t rep_bytes = ((sizeof(Shared) + 63) & ~size_t(63)) + (size_t)tcap * sizeof(av_track_row);
     size_t lds_t = rep_bytes * STEP_NW + chunk_bytes + 2 * 576;
-    if (seq_flags) {                  // + the copy of the stream's header and rows the overlapped step runs on
-        lds_t = (lds_t + 15) & ~size_t(15);
-        a.stage_off = (int)lds_t;
-        lds_t += HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row);
-    }
+    lds_t = (lds_t + 15) & ~size_t(15);      // + the copy of the stream's header and rows the tracker role runs on
+    a.stage_off = (int)lds_t;
+    lds_t += HDR_INTS * 4 + (size_t)tcap * sizeof(av_track_row);
+    // Waves per workgroup: sixteen (the planner's 21 trajectories in two rounds) unless that many launches in flight would not all be
+    // resident -- every one of them may be waiting for the one before it, so `depth` launches of 2 S workgroups must fit on the
+    // device together -- in which case eight (three rounds, twice the workgroups per CU).  AVHOT_STEP_PW=8|16 forces one.
     const char* pwe = getenv("AVHOT_STEP_PW");
-    const int pw = pwe && atoi(pwe) == 8 ? 8 : 16;
-    const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, pw) * 8;
-    const size_t lds = lds_t > lds_p ? lds_t : lds_p;
+    int pw = pwe && atoi(pwe) == 8 ? 8 : 16;
+    size_t lds = 0;
+    for (;;) {
+        const size_t lds_p = plan_lds_doubles(1, ctx->n_points, ctx->n_cand, pw) * 8;
+        lds = lds_t > lds_p ? lds_t : lds_p;
+        if (depth <= 1) break;
+        int per_cu = 0;
+        if (pw == 16) AV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hot_step_kernel<16>, 16 * 64, lds));
+        else AV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hot_step_kernel<8>, 8 * 64, lds));
+        if ((long long)depth * 2 * n_streams <= (long long)per_cu * ctx->n_cus) break;
+        AV_REQUIRE(pw == 16 && !pwe, AV_EINVAL, "av_hot_step: %d launches of %d workgroups in flight do not fit the device (%d per CU x %d CUs)",
+                   depth, 2 * n_streams, per_cu, ctx->n_cus);
+        pw = 8;
+    }
     // static __shared__ of the kernel (the Kalman bodies' arrays) counts against the same 64 KB
     static const size_t lds_static = [] {
         hipFuncAttributes fa{};
@@ -252,13 +263,13 @@ static int hot_step_launch(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg
                            double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
                            int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
                            double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0, int32_t* seq_flags,
-                           int seq) {
+                           int seq, int depth = 1) {
     StepArgs a;
     size_t lds;
     int pw;
     const int rc = hot_step_args(ctx, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
                                  tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
-                                 frame0, seq_flags, seq, a, lds, pw);
+                                 frame0, seq_flags, seq, a, lds, pw, depth);
     return rc != AV_OK ? rc : hot_step_go(a, lds, pw, stream);
 }
 
@@ -277,37 +288,41 @@ extern "C" int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker
                                double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n,
                                int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
                                double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0,
-                               int32_t* seq_flags, int seq) {
-    AV_REQUIRE(seq_flags && seq >= 0, AV_EINVAL, "av_hot_step_seq: needs the sequence flags (AV_STEP_FLAG_INTS(n_streams) zeroed int32) and seq >= 0");
+                               int32_t* seq_flags, int seq, int depth) {
+    AV_REQUIRE(seq_flags && seq >= 0, AV_EINVAL, "av_hot_step_seq: needs the sequence flags (AV_STEP_FLAG_INTS(n_streams) int32) and seq >= 0");
+    AV_REQUIRE(depth >= 2 && depth <= AV_STEP_MAX_DEPTH, AV_EINVAL, "av_hot_step_seq: depth %d not in [2, %d]", depth, AV_STEP_MAX_DEPTH);
     return hot_step_launch(ctx, stream, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
                            tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
-                           frame0, seq_flags, seq);
+                           frame0, seq_flags, seq, depth);
 }
 
-extern "C" int av_hot_steps_seq(av_ctx* ctx, av_stream_t stream_even, av_stream_t stream_odd, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg,
+extern "C" int av_hot_steps_seq(av_ctx* ctx, int depth, const av_stream_t* streams, const av_tracker_cfg* tcfg, const av_kf_cfg* kcfg,
                                 int n_streams, int h, int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_status,
-                                void* tracker_state, double* kf_state, const av_step_set* set_even, const av_step_set* set_odd,
-                                const double* z_steps, void* wire_steps, int stream0, int frame0, int32_t* seq_flags, int seq0, int n_steps) {
-    AV_REQUIRE(seq_flags && seq0 >= 0 && n_steps > 0 && set_even && set_odd, AV_EINVAL, "av_hot_steps_seq: bad argument");
-    AV_REQUIRE(stream_even != stream_odd, AV_EINVAL, "av_hot_steps_seq: the two parities need two different HIP streams");
-    StepArgs par[2];
+                                void* tracker_state, double* kf_state, const av_step_set* sets, const double* z_steps, void* wire_steps,
+                                int stream0, int frame0, int32_t* seq_flags, int seq0, int n_steps) {
+    AV_REQUIRE(seq_flags && seq0 >= 0 && n_steps > 0 && sets && streams, AV_EINVAL, "av_hot_steps_seq: bad argument");
+    AV_REQUIRE(depth >= 2 && depth <= AV_STEP_MAX_DEPTH, AV_EINVAL, "av_hot_steps_seq: depth %d not in [2, %d]", depth, AV_STEP_MAX_DEPTH);
+    for (int k = 0; k < depth; ++k)
+        for (int j = 0; j < k; ++j)
+            AV_REQUIRE(streams[k] != streams[j], AV_EINVAL, "av_hot_steps_seq: the %d steps in flight need %d different HIP streams", depth, depth);
+    StepArgs par[AV_STEP_MAX_DEPTH];
     size_t lds = 0;
     int pw = 16;
-    for (int k = 0; k < 2; ++k) {
-        const av_step_set& b = k ? *set_odd : *set_even;
+    for (int k = 0; k < depth; ++k) {
+        const av_step_set& b = sets[k];
         const int rc = hot_step_args(ctx, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, b.det_n, b.det_box, b.det_cls, b.det_conf, det_status,
                                      tracker_state, b.snap, b.snap_n, b.det2trk, z_steps ? z_steps : b.z, kf_state, b.vstate, b.plan_state,
-                                     b.waypoints, b.cost, b.order, wire_steps, stream0, frame0, seq_flags, seq0, par[k], lds, pw);
+                                     b.waypoints, b.cost, b.order, wire_steps, stream0, frame0, seq_flags, seq0, par[k], lds, pw, depth);
         if (rc != AV_OK) return rc;
     }
     const size_t zb = (size_t)n_streams * 4, wb = (size_t)n_streams * (AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES);
     for (int i = 0; i < n_steps; ++i) {
-        const int q = seq0 + i, k = q & 1;
+        const int q = seq0 + i, k = q % depth;
         StepArgs& a = par[k];
         a.seq = q;
         if (z_steps) a.z = z_steps + (size_t)i * zb;
         if (wire_steps) a.wire = (uint8_t*)wire_steps + (size_t)i * wb;
-        const int rc = hot_step_go(a, lds, pw, k ? stream_odd : stream_even);
+        const int rc = hot_step_go(a, lds, pw, streams[k]);
         if (rc != AV_OK) return rc;
     }
     return AV_OK;

@@ -102,9 +102,11 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                                const double* __restrict__ det_conf, int tcap, unsigned char* __restrict__ state_all,
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
                                int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
-                               const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr) {
-    // init_src: where the stream's header and rows are read from at entry instead of its state record (the overlapped time-step of
-    // step.hip hands over a copy it fetched with device-scope loads); everything is written to the state record as always
+                               const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr,
+                               const bool coherent_out = false) {
+    // init_src: where the stream's header and rows are read from at entry instead of its state record (the one-launch time-step of
+    // step.hip hands over an LDS copy); everything is written to the state record as always -- coherent_out: with device-scope
+    // (write-through) stores, for a successor launch already in flight, possibly on another XCD
     constexpr bool REPL = REP > 1;
     static_assert(!(REPL && MULTIWAVE), "replica waves hold the whole table: tcap must be 64");
     static_assert(REP == 1 || REP == 8, "the exchange buffers are laid out for 8 columns");
@@ -675,7 +677,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
         g.age = r.age, g.hits = r.hits, g.misses = r.misses, g.slot = r.slot, g.hist_len = r.hlen;
         g.flags = (r.hits >= cfg.min_hits) ? 1 : 0;
         g.conf = r.conf, g.vx = r.vx, g.vy = r.vy;
-        if (init_src) {               // overlapped steps: the successor may run on another XCD -- device-scope (write-through) stores
+        if (coherent_out) {
             unsigned long long w[sizeof(av_track_row) / 8];
             __builtin_memcpy(w, &g, sizeof(g));
             unsigned long long* d = reinterpret_cast<unsigned long long*>(rows + row);
@@ -686,7 +688,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
         }
     }
     if (row == 0) {
-        if (init_src) {
+        if (coherent_out) {
             const int hv[4] = {T, next_id, frame_count, status};
 #pragma unroll
             for (int i = 0; i < 4; ++i) __hip_atomic_store(hdr + i, hv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -194,8 +194,8 @@ class TrackTableExchange:
         (HotLoop.enqueue_steps), every step's wire tables written by the step kernels straight into the send buffer -- and its
         all-gather.  Replaces `bucket` rounds of begin_step() / enqueue_step() / exchange()."""
         loop = self.loop
-        if getattr(loop, "overlap", 1) != 2 or not self.prepacked:
-            raise RuntimeError("step_bucket needs HotLoop(window=1, overlap=2)")
+        if getattr(loop, "overlap", 1) < 2 or not self.prepacked:
+            raise RuntimeError("step_bucket needs HotLoop(window=1, overlap=2..)")
         if self.k % self.bucket:
             raise RuntimeError("step_bucket: a bucket is being filled step by step (%d of %d)" % (self.k % self.bucket, self.bucket))
         b = (self.k // self.bucket) & 1

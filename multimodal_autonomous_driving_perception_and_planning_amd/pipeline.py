@@ -84,17 +84,24 @@ class HotLoop:
         self.wire = None                  # set_wire(): the fused step also writes every stream's table in wire format
         self._wire_ids = (0, 0)
         self.overlap = int(overlap)
-        if self.overlap not in (1, 2):
-            raise ValueError("overlap is 1 or 2")
-        if self.overlap == 2:
+        if self.overlap not in (1, 2, 3, 4):
+            raise ValueError("overlap is 1 .. 4")
+        if self.overlap > 1:
             if not self.fused_step:
                 raise ValueError("overlap=2 needs the fused step (window 1, tcap 64, dcap 7..8, iou_threshold > 0)")
             names = [k for k in self._PER_STEP if getattr(self, k) is not None]
-            self._sets = [{k: getattr(self, k) for k in names}, {k: torch.zeros_like(getattr(self, k)) for k in names}]
-            self._pstreams = [self.stream, torch.cuda.Stream(device=d)]
+            self._sets = [{k: getattr(self, k) for k in names}] + [{k: torch.zeros_like(getattr(self, k)) for k in names}
+                                                                   for _ in range(self.overlap - 1)]
+            self._pstreams = [self.stream] + [torch.cuda.Stream(device=d) for _ in range(self.overlap - 1)]
             self.seq_flags = torch.zeros(65 * S + 32, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
             self._seq = 0
             self._csets = None
+            self.reset()
+            try:                              # (one step now: the library refuses a depth whose launches would not all be resident)
+                self._enqueue_step_seq()
+                self.synchronize()
+            except RuntimeError as e:
+                raise ValueError("overlap=%d: %s" % (self.overlap, e)) from None
         self.reset()
 
     _PER_STEP = ("det_n", "det_box", "det_cls", "det_conf", "snap", "snap_n", "det2trk", "z", "vstate", "plan_state", "wp",
@@ -107,12 +114,12 @@ class HotLoop:
 
     def _serial_only(self, what):
         if self.overlap != 1:
-            raise RuntimeError("%s is not available with overlap=2 (only the one-launch step is ordered across the two streams)" % what)
+            raise RuntimeError("%s is not available with overlap=2.. (only the one-launch step is ordered across the loop's streams)" % what)
 
     def reset(self, frame_offsets=None):
         """Resets every stream (tracker.reset(), state_estimator.reset(), detector.reset())."""
         h, L = self.ctx.handle, self.L
-        if self.overlap == 2:
+        if self.overlap > 1:
             for st in self._pstreams:
                 st.synchronize()
         nat.check(L.av_tracker_reset(h, self._s, self.S, self.tcap, self.tcfg.trajectory_length, nat.ptr(self.trk_state)))
@@ -122,10 +129,10 @@ class HotLoop:
                 self.frame_count.zero_()
             else:
                 self.frame_count.copy_(torch.as_tensor(np.asarray(frame_offsets, np.int32)), non_blocking=False)
-            if self.overlap == 2:
+            if self.overlap > 1:
                 self.seq_flags.zero_()
                 self.seq_flags[64 * self.S + 32:].copy_(self.frame_count)
-        if self.overlap == 2:
+        if self.overlap > 1:
             self._seq = 0
             self.__dict__.update(self._sets[0])
         self.stream.synchronize()
@@ -133,13 +140,13 @@ class HotLoop:
     def load_measurements(self, z, all_sets=False):
         """z: float64 [S, W, 4] ego measurements for the next window (host array).  overlap=2: for the next STEP (its buffer
         set); all_sets=True: for every step from now on (both sets)."""
-        if self.overlap == 2:                 # the next step's set, on the next step's stream
+        if self.overlap > 1:                  # the next step's set, on the next step's stream
             zt = torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4)
-            for k in ((self._seq & 1, (self._seq + 1) & 1) if all_sets else (self._seq & 1,)):
+            for k in (range(self.overlap) if all_sets else (self._seq % self.overlap,)):
                 with torch.cuda.stream(self._pstreams[k]):
                     self._sets[k]["z"].copy_(zt)
                 self._pstreams[k].synchronize()
-            self.z = self._sets[self._seq & 1]["z"]
+            self.z = self._sets[self._seq % self.overlap]["z"]
             return
         with torch.cuda.stream(self.stream):
             self.z.copy_(torch.as_tensor(np.ascontiguousarray(z, np.float64)).view(self.S, self.W, 4))
@@ -245,7 +252,7 @@ class HotLoop:
 
     def enqueue_step_fused(self, stream=None):
         """Window 1: detect + track + Kalman + plan of one frame of every stream as ONE launch."""
-        if self.overlap == 2:
+        if self.overlap > 1:
             return self._enqueue_step_seq(stream)
         nat.check(self.L.av_hot_step(self.ctx.handle, stream or self._s, C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h,
                                      self.w, self.dcap, self.tcap, nat.ptr(self.frame_count), nat.ptr(self.det_n),
@@ -256,11 +263,11 @@ class HotLoop:
                                      nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1]))
 
     def _enqueue_step_seq(self, stream=None):
-        """overlap=2: step number self._seq on stream seq % 2 with buffer set seq % 2, ordered behind step seq - 1 per stream and
+        """overlap=D: step number self._seq on stream seq % D with buffer set seq % D, ordered behind step seq - 1 per stream and
         role by the sequence flags (av_hot_step_seq)."""
         if stream is not None:
-            raise RuntimeError("overlap=2 launches on the loop's own pair of streams")
-        k = self._seq & 1
+            raise RuntimeError("overlap=2.. launches on the loop's own streams")
+        k = self._seq % self.overlap
         b = self._sets[k]
         self.__dict__.update(b)              # the attributes name the set of the step enqueued last
         nat.check(self.L.av_hot_step_seq(self.ctx.handle, C.c_void_p(self._pstreams[k].cuda_stream), C.byref(self.tcfg), C.byref(self.kcfg),
@@ -269,7 +276,7 @@ class HotLoop:
                                          nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(b.get("snap")), nat.ptr(b.get("snap_n")),
                                          nat.ptr(b["det2trk"]), nat.ptr(b["z"]), nat.ptr(self.kf_state), nat.ptr(b["vstate"]),
                                          nat.ptr(b["plan_state"]), nat.ptr(b.get("wp")), nat.ptr(b["cost"]), nat.ptr(b["order"]),
-                                         nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq))
+                                         nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq, self.overlap))
         self._seq += 1
 
     def enqueue_steps(self, n_steps, z_steps=None, wire_steps=None):
@@ -277,32 +284,67 @@ class HotLoop:
         z_steps: None (every step reads its buffer set's z) or a float64 device tensor [n_steps, S, 4], the measurements of each
         step; wire_steps: None or a uint8 device tensor [n_steps, S, av_wire_table_bytes(tcap)] that receives every step's
         wire tables (set_wire's stream0 / frame0 apply)."""
-        if self.overlap != 2:
-            raise RuntimeError("enqueue_steps needs overlap=2")
+        if self.overlap < 2:
+            raise RuntimeError("enqueue_steps needs overlap=2..")
         if n_steps <= 0:
             return
         if self._csets is None:
             def cset(b):
                 m = {"wp": "waypoints"}
                 return nat.StepSet(**{m.get(k, k): (b[k].data_ptr() if b.get(k) is not None else None) for k in self._PER_STEP})
-            self._csets = [cset(b) for b in self._sets]
+            self._csets = (nat.StepSet * self.overlap)(*[cset(b) for b in self._sets])
+            self._cstreams = (C.c_void_p * self.overlap)(*[st.cuda_stream for st in self._pstreams])
         if z_steps is not None and (z_steps.dtype != torch.float64 or z_steps.numel() != n_steps * self.S * 4 or not z_steps.is_contiguous()):
             raise ValueError("z_steps: contiguous float64 [n_steps, S, 4]")
         if wire_steps is not None:
             wb = int(self.L.av_wire_table_bytes(self.tcap))
             if not (self.keep_snapshots and wire_steps.dtype == torch.uint8 and wire_steps.numel() == n_steps * self.S * wb and wire_steps.is_contiguous()):
                 raise ValueError("wire_steps: contiguous uint8 [n_steps, S, %d] (and keep_snapshots=True)" % wb)
-        nat.check(self.L.av_hot_steps_seq(self.ctx.handle, C.c_void_p(self._pstreams[0].cuda_stream), C.c_void_p(self._pstreams[1].cuda_stream),
+        nat.check(self.L.av_hot_steps_seq(self.ctx.handle, self.overlap, self._cstreams,
                                           C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h, self.w, self.dcap, self.tcap,
                                           nat.ptr(self.frame_count), nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(self.kf_state),
-                                          C.byref(self._csets[0]), C.byref(self._csets[1]), nat.ptr(z_steps), nat.ptr(wire_steps),
+                                          self._csets, nat.ptr(z_steps), nat.ptr(wire_steps),
                                           self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq, int(n_steps)))
         self._seq += int(n_steps)
-        self.__dict__.update(self._sets[(self._seq - 1) & 1])
+        self.__dict__.update(self._sets[(self._seq - 1) % self.overlap])
+
+    def tune_streams(self, pool=8, candidates=12, steps=600):
+        """overlap=D: pick the D HIP streams the overlapped steps run on.  The runtime serves a process's streams from a few hardware
+        queues, assigned by the process's whole stream history; launches on streams that share a queue do not overlap, and the same
+        64-stream loop at depth 4 was measured at 4.9 us per step in one process and 10 us in another.  There is no way to ask for a
+        queue, so the loop measures: `steps` steps (one library call) on each of `candidates` sets of D streams drawn from `pool`
+        fresh ones, and keeps the fastest set.  Call it before reset() / loading state: the measured steps advance the streams'
+        state, and the loop is reset afterwards.  -> us per step of every candidate set."""
+        import time
+        if self.overlap < 2:
+            return []
+        self.synchronize(check=False)
+        D = self.overlap
+        fresh = [torch.cuda.Stream(device=self.dev) for _ in range(max(pool, D))]
+        rs = np.random.RandomState(12345)
+        sets = [list(self._pstreams)] + [fresh[i:i + D] for i in range(0, len(fresh) - D + 1, D)]
+        while len(sets) < candidates:
+            sets.append([fresh[i] for i in sorted(rs.choice(len(fresh), D, replace=False))])
+        tried = []
+        for cand in sets:
+            self._pstreams, self.stream = list(cand), cand[0]
+            self._csets = None
+            self.reset()
+            self.enqueue_steps(64)
+            self.synchronize()
+            t0 = time.perf_counter()
+            self.enqueue_steps(steps)
+            self.synchronize()
+            tried.append(((time.perf_counter() - t0) / steps * 1e6, cand))
+        best = min(tried, key=lambda x: x[0])
+        self._pstreams, self.stream = list(best[1]), best[1][0]
+        self._csets = None
+        self.reset()
+        return [round(t, 2) for t, _ in tried]
 
     def step_stream(self):
         """The torch stream the step enqueued last runs on (overlap=2 alternates between two)."""
-        return self._pstreams[(self._seq - 1) & 1] if self.overlap == 2 and self._seq else self.stream
+        return self._pstreams[(self._seq - 1) % self.overlap] if self.overlap > 1 and self._seq else self.stream
 
     def enqueue_step(self):
         """One window of the whole loop: fork{detect; track} || {kf; plan}; join.  Detections only feed the
@@ -348,12 +390,12 @@ class HotLoop:
             self.synchronize()
 
     def synchronize(self, check=True):
-        if self.overlap == 2:
+        if self.overlap > 1:
             for st in self._pstreams:
                 st.synchronize()
             if check and int(self.seq_flags[64 * self.S].item()) != 0:
-                raise RuntimeError("HotLoop(overlap=2): a step waited in vain for its predecessor (sequence flags: fault word set); "
-                                   "the state is no longer that of a serial run -- reset()")
+                raise RuntimeError("HotLoop(overlap=%d): a step waited in vain for its predecessor (sequence flags: fault word set); "
+                                   "the state is no longer that of a serial run -- reset()" % self.overlap)
             return
         self.stream.synchronize()
 

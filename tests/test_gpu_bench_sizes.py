@@ -335,7 +335,7 @@ def test_bucketed_gather_around_the_fused_step(torch, oracle_streams):
 
 
 def test_overlapped_loop_headline_size_against_the_oracle_and_its_bucketed_gather(torch, oracle_streams):
-    """The default bench: HotLoop(64, window 1, overlap=2), buckets of 8 time-steps enqueued by one library call each
+    """The default bench: HotLoop(64, window 1, overlap=4), buckets of 8 time-steps enqueued by one library call each
     (TrackTableExchange.step_bucket -> av_hot_steps_seq), the step kernels writing every step's wire tables into the send buffer.
     Every gathered table of every stream and time-step against the CPU oracle of the loop (ids, live count, frame stamp), fresh
     measurements every step, nothing synchronised inside a bucket; then the same through the step-by-step calls."""
@@ -351,7 +351,7 @@ def test_overlapped_loop_headline_size_against_the_oracle_and_its_bucketed_gathe
     zs = torch.as_tensor(np.ascontiguousarray(z.transpose(1, 0, 2))).cuda()     # [T, S, 4]
     try:
         for mode in ("bucket calls", "step by step"):
-            loop = HotLoop(n_streams=S, window=1, keep_waypoints=True, overlap=2)
+            loop = HotLoop(n_streams=S, window=1, keep_waypoints=True, overlap=4)
             loop.reset(frame_offsets=[17 * s for s in range(S)])
             x = D.TrackTableExchange(loop, 1, 0, per_frame=True, bucket=K)
             try:

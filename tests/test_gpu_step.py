@@ -125,7 +125,8 @@ def _valid_rows(o):
     return o
 
 
-def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch, depth):
     """HotLoop(overlap=2): consecutive steps on two HIP streams, ordered per stream and role by the device-side sequence flags
     (av_hot_step_seq).  (a) enqueued back to back without any host synchronisation -- the case the flags exist for -- every
     step's wire table (one buffer per step) and the state after the last step equal the serial loop's; (b) synchronised step by
@@ -138,14 +139,14 @@ def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
     z = np.stack([run_stream(steps, frame_offset=offs[s], ego_seed=s)["z"] for s in range(S)])       # [S, steps, 4]
     wb = int(nat.lib().av_wire_table_bytes(64))
     serial = HotLoop(n_streams=S, window=1)
-    over = HotLoop(n_streams=S, window=1, overlap=2)
-    assert serial.fused_step and over.overlap == 2
+    over = HotLoop(n_streams=S, window=1, overlap=depth)
+    assert serial.fused_step and over.overlap == depth
     # (a) constant measurements (the step reads z from its buffer set; both sets are loaded once), no host synchronisation
     wires = {}
     for name, lp in (("serial", serial), ("over", over)):
         lp.reset(frame_offsets=offs)
         w = torch.zeros(steps, S, wb, dtype=torch.uint8, device=lp.dev)
-        lp.load_measurements(z[:, :1], **({"all_sets": True} if lp.overlap == 2 else {}))
+        lp.load_measurements(z[:, :1], **({"all_sets": True} if lp.overlap > 1 else {}))
         for t in range(steps):
             lp.set_wire(w[t], stream0=40, frame0=1000)
             lp.enqueue_step()
@@ -185,6 +186,8 @@ def test_overlapped_steps_equal_the_serial_loop_bit_for_bit(torch):
         over.enqueue_track()
     with pytest.raises(RuntimeError, match="overlap=2"):
         over.step(graph=True)
+    with pytest.raises(ValueError, match="do not fit"):
+        HotLoop(n_streams=128, window=1, overlap=3)
 
 
 def test_overlapped_step_without_its_predecessor_faults_instead_of_hanging(torch, monkeypatch):

@@ -24,7 +24,7 @@ for K in (() if os.environ.get("SKIPK") else (1, 2, 3, 4)):
     print("K=%d loops in turn: host enqueue %.2f us/launch, until the device is done %.2f us/launch" % (K, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
     del loops
 
-for ov in (1, 2):
+for ov in (1, 2, 3):
     lp = HotLoop(n_streams=S, window=1, overlap=ov)
     lp.load_measurements(z, **({"all_sets": True} if ov == 2 else {}))
     for _ in range(200): lp.enqueue_step()
@@ -37,13 +37,16 @@ for ov in (1, 2):
     t2 = time.perf_counter()
     print("HotLoop(overlap=%d): host enqueue %.2f us/step, until the device is done %.2f us/step" % (ov, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
 
-lp = HotLoop(n_streams=S, window=1, overlap=2)
-lp.load_measurements(z, all_sets=True)
-lp.enqueue_steps(200); lp.synchronize()
-for N in (4000, 20000):
-    t0 = time.perf_counter()
-    lp.enqueue_steps(N)
-    t1 = time.perf_counter()
-    lp.synchronize()
-    t2 = time.perf_counter()
-    print("HotLoop(overlap=2).enqueue_steps(%d): host enqueue %.2f us/step, until the device is done %.2f us/step" % (N, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
+for D in (2, 3, 4):
+    lp = HotLoop(n_streams=S, window=1, overlap=D)
+    if os.environ.get("TUNE"): print("  stream sets tried, us/step:", lp.tune_streams())
+    lp.load_measurements(z, all_sets=True)
+    lp.enqueue_steps(200); lp.synchronize()
+    for N in (4000,):
+        t0 = time.perf_counter()
+        lp.enqueue_steps(N)
+        t1 = time.perf_counter()
+        lp.synchronize()
+        t2 = time.perf_counter()
+        print("HotLoop(overlap=%d).enqueue_steps(%d): host enqueue %.2f us/step, until the device is done %.2f us/step" % (D, N, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6), flush=True)
+    del lp
