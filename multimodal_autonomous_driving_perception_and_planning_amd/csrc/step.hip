@@ -72,6 +72,8 @@ __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) 
         int ok = 0;
         for (int n = 0; n <= a.spin; ++n) {
             if (__hip_atomic_load(a.flags + 32 * slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.seq) { ok = 1; break; }
+            // (once any wait has run out the chain is broken for good: the launches behind it give up at once instead of one timeout each)
+            if ((n & 255) == 255 && __hip_atomic_load(a.flags + flag_fault(a.S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) atomicOr(a.flags + flag_fault(a.S), 1);

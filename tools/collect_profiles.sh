@@ -17,12 +17,17 @@ if [ "$ONLY" = yolo ]; then
   pmc yolo_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" python3 tools/ybench.py --batch 64 --reps 3
   ls $OUT; exit 0
 fi
-# the headline (config 4 as worded: one hot_step_kernel launch per time-step) and its 256-frame-window throughput form
+# the headline (config 4 as worded: one hot_step_kernel launch per time-step, up to four in flight), the same with serial launches,
+# and the 256-frame-window throughput form
+if [ "$ONLY" != rest ]; then
 trace bench_config4 python3 bench.py --no-also --no-cpu-baseline --min-seconds 0.02
+trace bench_config4_serial python3 bench.py --no-also --no-cpu-baseline --overlap 1 --min-seconds 0.02
 trace bench_config4_window256 python3 bench.py --no-also --no-cpu-baseline --window 256 --min-seconds 0.02
 trace bench_config2 python3 bench.py --no-also --no-cpu-baseline --workload config2 --steps 4 --warmup 1 --window 32768 --min-seconds 0.02
-pmc step_fetch FETCH_SIZE python3 bench.py --no-also --no-cpu-baseline --min-seconds 0.005 --steps 5
-pmc step_write WRITE_SIZE python3 bench.py --no-also --no-cpu-baseline --min-seconds 0.005 --steps 5
+fi
+# (counter passes run kernels one after the other in any order: the overlapped steps are launched one at a time, tools/stepsync.py)
+pmc step_fetch FETCH_SIZE python3 tools/stepsync.py 300
+pmc step_write WRITE_SIZE python3 tools/stepsync.py 300
 pmc trk_fetch FETCH_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2
 pmc trk_write WRITE_SIZE python3 tools/kbench.py --streams 64 --window 256 --stages detect,track --reps 2
 if [ "$ONLY" = hot ]; then ls $OUT; exit 0; fi

@@ -62,7 +62,7 @@ def counters(name):
     return out
 
 
-for nm in ("bench_config4", "bench_config4_window256", "bench_config3", "bench_config2", "lane_S64", "yolo_b64", "yolo_b64_fp32", "yolo_b1_frame"):
+for nm in ("bench_config4", "bench_config4_serial", "bench_config4_window256", "bench_config3", "bench_config2", "lane_S64", "yolo_b64", "yolo_b64_fp32", "yolo_b1_frame"):
     stats(nm, "%s_%s_kernel_stats.csv" % (tag, nm))
 
 # ---- YOLO: launch-by-launch timeline of the last forward of the trace (tools/ytimeline.py) ---------------------------------
@@ -134,11 +134,13 @@ for k in fe:
 
 # ---- the one-launch time-step (headline): HBM bytes per launch ------------------------------------------------------------------
 fe, wr = counters("step_fetch"), counters("step_write")
-for k in fe:
-    if "hot_step_kernel" in k and k in wr:
+_hs = [k for k in fe if "hot_step_kernel" in k and k in wr]
+for k in sorted(_hs, key=lambda k: fe[k]["launches"])[-1:]:           # the instance the headline launches (eight waves per workgroup at depth 4)
+    if True:
         f, w_ = 2.0 * fe[k]["FETCH_SIZE"] * 1024.0, wr[k]["WRITE_SIZE"] * 1024.0
         json.dump({"kernel": k, "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, each with --kernel-trace only) -- "
-                                          "python3 bench.py --no-also --no-cpu-baseline (64 streams, one launch per time-step), MI355X, " + tag,
+                                          "python3 bench.py --no-also --no-cpu-baseline (64 streams, one launch per time-step, up to 4 steps in flight; "
+                                          "the counter passes run the launches one after the other), MI355X, " + tag,
                    "streams_per_launch": 64, "WRITE_SIZE_KiB": wr[k]["WRITE_SIZE"], "FETCH_SIZE_KiB_raw": fe[k]["FETCH_SIZE"],
                    "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)", "hbm_bytes_per_launch": int(f + w_),
                    "hbm_bytes_per_stream_step": round((f + w_) / 64.0, 1), "algorithmic_bytes_per_stream_step": 4776 + 768 + 228 + 51660,
