@@ -495,7 +495,7 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
  * `depth` = D: up to D launches may be in flight, each possibly waiting for the one before it, so all of them must be RESIDENT
  * together: the call picks sixteen or eight waves per workgroup accordingly and returns AV_EINVAL when D launches of 2 S workgroups
  * cannot fit (64 streams: D <= 2 with sixteen waves, <= 4 with eight).  HotLoop(window=1, overlap=D) drives it. */
-#define AV_STEP_FLAG_INTS(n_streams) (65 * (n_streams) + 32)
+#define AV_STEP_FLAG_INTS(n_streams) (65 * (n_streams) + 32 + 64)
 int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_cfg, const av_kf_cfg* kf_cfg, int n_streams, int h,
                     int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_n, int32_t* det_box, int32_t* det_cls,
                     double* det_conf, int32_t* det_status, void* tracker_state, av_track_row* snap, int32_t* snap_n, int32_t* det2trk,

@@ -66,6 +66,27 @@ constexpr int STEP_NW = 8;
 // the streams' detector frame counts at reset (the count before step q is base + q: the detections do not have to wait)
 __device__ __host__ inline int flag_fault(int S) { return 64 * S; }
 __device__ __host__ inline int flag_base(int S) { return 64 * S + 32; }
+__device__ __host__ inline int flag_stats(int S) { return 65 * S + 32; }      // 32 u64 of phase clocks (AVHOT_STEP_FENCE=8, tools/steptime.py)
+struct StepClock {                    // debug only: 100-MHz clock stamps of a role's thread 0, summed per phase over all launches
+    unsigned long long t;
+    bool on;
+    unsigned long long* acc;
+    __device__ void start(const StepArgs& a, int role);
+    __device__ void mark(int k) {
+        if (!on) return;
+        const unsigned long long n = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(acc + k, n - t);
+        t = n;
+    }
+};
+
+__device__ void StepClock::start(const StepArgs& a, int role) {
+    on = a.flags && (a.fence & 8) && threadIdx.x == 0;
+    if (!on) return;
+    acc = reinterpret_cast<unsigned long long*>(a.flags + flag_stats(a.S)) + role * 16;
+    t = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(acc + 15, 1ull);
+}
 
 __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) {
     if (threadIdx.x == 0) {
@@ -77,6 +98,13 @@ __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) 
             __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) atomicOr(a.flags + flag_fault(a.S), 1);
+        if (ok && (a.fence & 8) && a.seq > 0) {      // debug: publisher's clock at its counter store -> this poll's return
+            const unsigned long long tp = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.flags + 32 * slot + 2), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* acc = reinterpret_cast<unsigned long long*>(a.flags + flag_stats(a.S)) + (slot & 1) * 16;
+            if (now > tp) atomicAdd(acc + 8, now - tp), atomicAdd(acc + 9, 1ull);
+        }
         *go = ok;
     }
     __syncthreads();                  // (also keeps the compiler from moving any load of the role above the poll)
@@ -87,6 +115,9 @@ __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) 
 // by ONE thread, behind a workgroup barrier that follows the role's last (device-scope) store to its persistent state
 __device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
     if (a.fence & 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (a.fence & 8)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.flags + 32 * slot + 2), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.flags + 32 * slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // n8 8-byte words of a stream's record into LDS, by the first `nthreads` threads of the workgroup.  coherent: device-scope loads (the
@@ -105,6 +136,11 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int go, fc_stage;
     __shared__ __attribute__((aligned(16))) double kf_stage[AV_KF_STATE_DOUBLES + 2];
+    // the step's inputs that do not come from the previous step, in LDS before the wait: the frame's detections (made here, copied
+    // to their output arrays by the other threads) and the ego measurement
+    __shared__ __attribute__((aligned(16))) int d_box[8 * 4];
+    __shared__ __attribute__((aligned(16))) double d_conf[8], z_stage[4];
+    __shared__ int d_cls[8], d_n[1];
     const int tid = threadIdx.x;
     const bool seq = a.flags != nullptr;          // consecutive steps overlapped: wait for / publish to the neighbouring launches
     // Both roles run on an LDS copy of the stream's record (tracker: header + rows; Kalman: the filter's 46 doubles), fetched by the
@@ -112,16 +148,30 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     if ((int)blockIdx.x < a.S) {
         if (PW > STEP_NW && tid >= STEP_NW * 64) return;
         const int s = blockIdx.x;
+        StepClock ck;
+        ck.start(a, 0);
         // the detections first: overlapped, the detector's count before step q is its count at reset + q -- no need to wait for step
         // q - 1 (tid 0 checks that against the counter the predecessor left: fault bit 1)
         int fc_before = 0;
         if (tid == 0) {
             fc_before = seq ? a.flags[flag_base(a.S) + s] + a.seq : a.frame_count[s];
             fc_stage = fc_before;
-            simdet_frame<true>(s, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, a.det_n, a.det_box, a.det_cls, a.det_conf,
+            simdet_frame<true>(0, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, d_n, d_box, d_cls, d_conf,
                                a.det_status ? a.det_status + s : nullptr);
         }
-        if (seq && !seq_enter(a, 2 * s, &go)) return;
+        ck.mark(0);                   // detections made
+        if (seq) {
+            if (!seq_enter(a, 2 * s, &go)) return;
+        } else {
+            __syncthreads();
+        }
+        ck.mark(1);                   // waited for the predecessor
+        if (tid < a.dcap) {           // the detections' output arrays (the tracker reads the LDS copy)
+            reinterpret_cast<int4*>(a.det_box)[(size_t)s * a.dcap + tid] = reinterpret_cast<const int4*>(d_box)[tid];
+            a.det_cls[(size_t)s * a.dcap + tid] = d_cls[tid];
+            a.det_conf[(size_t)s * a.dcap + tid] = d_conf[tid];
+            if (tid == 0) a.det_n[s] = d_n[0];
+        }
         unsigned char* stage = smem + a.stage_off;
         int fc0 = 0;
         if (seq && tid == 0) fc0 = __hip_atomic_load(a.frame_count + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (in flight with the table)
@@ -136,30 +186,37 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             }
         }
         __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0)); the table copy is in LDS
-        tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, a.det_n, a.det_box, a.det_cls, a.det_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
-                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq);
+        ck.mark(2);                   // record in LDS
+        tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
+                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0);
+        ck.mark(3);                   // tracker frame (thread 0's wave)
+        if (seq || a.wire) __syncthreads();      // every wave's stores (table, rings, counters, snapshot rows) are complete
+        ck.mark(4);                   // all waves done, stores acknowledged
+        // the successor may start before the wire table is written: the steps in flight have wire buffers of their own
+        if (seq && tid == 0) seq_leave(a, 2 * s);
+        ck.mark(5);
         if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
-            __syncthreads();          // the snapshot rows the bookkeeper wave wrote
             // frame = frame0 + the stream's detector frame count after this step (a captured graph -- fixed kernel arguments -- stamps
             // every replay with its own index)
             if (tid < a.tcap)
                 wire_put(a.wire + (size_t)s * (AV_WIRE_HDR_BYTES + (size_t)a.tcap * AV_WIRE_ROW_BYTES), tid, a.snap_n[s], a.tcap,
                          a.snap + (size_t)s * a.tcap, a.stream0 + s, a.frame0 + fc_stage);
         }
-        if (seq) {
-            __syncthreads();          // every wave's stores (table, rings, counters, outputs) are complete
-            if (tid == 0) seq_leave(a, 2 * s);
-        }
     } else {
         const int s = blockIdx.x - a.S;
+        StepClock ck;
+        ck.start(a, 1);
+        if (tid < 4) z_stage[tid] = a.z[(size_t)s * 4 + tid];
         if (seq && !seq_enter(a, 2 * s + 1, &go)) return;
+        ck.mark(1);
         if (tid < 64) {
             double* rec = a.kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
             fetch_record(rec, kf_stage, AV_KF_STATE_DOUBLES, 64, seq);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const double* z = a.z + (size_t)s * 4;
+            ck.mark(2);
+            const double* z = z_stage;
             double *vs = a.vstate + (size_t)s * AV_VSTATE_DOUBLES, *ps = a.plan_state + (size_t)s * 4;
             const bool separable = kf_axis_body(a.kcfg, 1, z, nullptr, kf_stage, vs, ps, 0, tid);
             if (!separable && tid == 0) kf_dense_stream_lds(a.kcfg, 0, 1, z, nullptr, kf_stage, vs, ps);   // (LDS form: kf_dense.inc)
@@ -174,9 +231,12 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
                     rec[tid] = kf_stage[tid];
             }
         }
+        ck.mark(3);                   // Kalman step + record written
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
+        ck.mark(4);
         if (seq && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
         plan_block<1, PW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
+        ck.mark(6);                   // planner (thread 0's wave)
     }
 }
 

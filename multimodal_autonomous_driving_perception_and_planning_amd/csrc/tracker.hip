@@ -103,7 +103,9 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
                                int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
                                const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr,
-                               const bool coherent_out = false) {
+                               const bool coherent_out = false, const long long det_sf0 = -1) {
+    // det_sf0 >= 0 (replica kernel): the detection arrays are indexed from this frame slot instead of s * n_frames (the one-launch
+    // time-step hands over the LDS copy its detector role wrote, slot 0)
     // init_src: where the stream's header and rows are read from at entry instead of its state record (the one-launch time-step of
     // step.hip hands over an LDS copy); everything is written to the state record as always -- coherent_out: with device-scope
     // (write-through) stores, for a successor launch already in flight, possibly on another XCD
@@ -205,7 +207,8 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
             pf_conf = det_conf[sf0 * dcap + tid];
         }
     };
-    if (REPL && n_frames > 0) prefetch((size_t)s * n_frames, n_frames < FC ? n_frames : FC);
+    const size_t dsf0 = det_sf0 >= 0 ? (size_t)det_sf0 : (size_t)s * n_frames;
+    if (REPL && n_frames > 0) prefetch(dsf0, n_frames < FC ? n_frames : FC);
     int fl = -1;                               // frame within the staged chunk
     // TIMED (AVHOT_TRACKER_TIMED, tools/ktime.py): cycles of every wave of stream 0 by phase, summed over the window, left in det2trk
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -405,7 +408,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                 c_cls[tid] = pf_cls, c_conf[tid] = pf_conf;
             }
             lds_sync<true>();
-            if (f + FC < n_frames) prefetch(sf + FC, (n_frames - f - FC) < FC ? (n_frames - f - FC) : FC);
+            if (f + FC < n_frames) prefetch(dsf0 + f + FC, (n_frames - f - FC) < FC ? (n_frames - f - FC) : FC);
         } else if (fl == 0) {
             // one cooperative load of the next FC frames' detections; the only global reads of the loop
             const int nfr = (n_frames - f) < FC ? (n_frames - f) : FC;

@@ -93,7 +93,7 @@ class HotLoop:
             self._sets = [{k: getattr(self, k) for k in names}] + [{k: torch.zeros_like(getattr(self, k)) for k in names}
                                                                    for _ in range(self.overlap - 1)]
             self._pstreams = [self.stream] + [torch.cuda.Stream(device=d) for _ in range(self.overlap - 1)]
-            self.seq_flags = torch.zeros(65 * S + 32, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
+            self.seq_flags = torch.zeros(65 * S + 32 + 64, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
             self._seq = 0
             self._csets = None
             self.reset()
@@ -131,7 +131,7 @@ class HotLoop:
                 self.frame_count.copy_(torch.as_tensor(np.asarray(frame_offsets, np.int32)), non_blocking=False)
             if self.overlap > 1:
                 self.seq_flags.zero_()
-                self.seq_flags[64 * self.S + 32:].copy_(self.frame_count)
+                self.seq_flags[64 * self.S + 32:65 * self.S + 32].copy_(self.frame_count)
         if self.overlap > 1:
             self._seq = 0
             self.__dict__.update(self._sets[0])
