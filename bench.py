@@ -263,6 +263,10 @@ def max_over_ranks(el, world):
 # ---------------------------------------------------------------------------------------------------------------
 # configs 2 / 4: simulated detection -> tracker || Kalman -> planner
 # ---------------------------------------------------------------------------------------------------------------
+class ChainBroken(RuntimeError):
+    """An overlapped HotLoop reported a step that waited in vain for its predecessor (on this rank or another)."""
+
+
 def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_reps=10, overlap=None):
     import numpy as np
     import torch
@@ -274,19 +278,31 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
 
     # window 1, launched (not graph-replayed): consecutive steps overlapped unless asked otherwise
     ov = (a.overlap if overlap is None else overlap) if (W == 1 and not graph and not a.taggers) else 1
-    fallback = None
+    def any_rank(flag):                  # the ranks decide together: a collective follows
+        if world > 1:
+            t = torch.tensor([int(bool(flag))], device=torch.device("cuda", local))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(int(t.item()))
+        return bool(flag)
+
+    # Overlapped launches need kernels of different streams to run concurrently; under a tool that runs one kernel at a time in an
+    # order of its own (rocprofv3 --pmc) a step waits in vain for its predecessor and the loop reports it (fault word): ChainBroken
+    # on every rank, and the caller measures with serial launches instead.
+    loop, tuned, why = None, None, None
     try:
         loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True, overlap=ov)
         # (which hardware queues the D streams got decides how the launches overlap)
         tuned = loop.tune_streams() if (loop.overlap > 1 and not a.no_tune) else None
     except (RuntimeError, ValueError) as e:
-        # overlapped launches need kernels of different streams to run concurrently; under a tool that runs one kernel at a time in an
-        # order of its own (rocprofv3 --pmc) a step waits in vain for its predecessor and the loop reports it: serial launches then
         if ov == 1:
             raise
-        fallback = str(e)[:200]
-        loop = HotLoop(n_streams=S, window=W, device=local, keep_waypoints=True, keep_snapshots=True, overlap=1)
-        tuned = None
+        why = str(e)
+    if ov > 1 and any_rank(why is not None):
+        raise ChainBroken(why or "another rank's overlapped loop reported a broken chain")
+
+    def chain_ok():
+        if loop.overlap > 1 and any_rank(int(loop.seq_flags[64 * S].item()) != 0):
+            raise ChainBroken("a step waited in vain for its predecessor")
     ov = loop.overlap
     L = nat.lib()
     g0 = rank * S                                      # global stream ids of this rank
@@ -348,7 +364,10 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     def drain():
         if not graph and not loop.fused_step:
             nat.check(L.av_join(h, s))       # main stream waits for the side stream's tail
-        loop.synchronize()
+        if loop.overlap > 1:
+            loop.synchronize(check=False)    # (the fault word is looked at by all ranks together: chain_ok)
+        else:
+            loop.synchronize()
         if xchg is not None:
             xchg.flush()                      # (a partially filled bucket)
             xchg.synchronize()
@@ -357,6 +376,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         one_step()
     drain()
     torch.cuda.synchronize()
+    chain_ok()
     # a probe of the step's duration (untimed) sizes the inner repetitions: every reported step = `reps` back-to-back steps
     tp = time.perf_counter()
     for _ in range(8):
@@ -377,6 +397,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
     el = time.perf_counter() - t0
     el, per_rank_ms = max_over_ranks(el, world)
     nsteps = calls * unit
+    chain_ok()
     # the tracker's sticky overflow flag: a truncated table would silently drop births (parity lost)
     hdr, _, _ = loop.tracker_tables()
     if int(np.abs(hdr[:, 3]).max()) != 0:
@@ -388,16 +409,17 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
         # waits for the predecessor; the step rate above is `ov` of these at a time.
         for _ in range(64):
             loop.enqueue_step()
-        loop.synchronize()
+        loop.synchronize(check=False)
         ev = Events(L, nat, 256)
         for e in ev.ev:
             st = C.c_void_p(loop._pstreams[loop._seq % ov].cuda_stream)
             nat.check(L.av_event_record(e[0], st))
             loop.enqueue_step()
             nat.check(L.av_event_record(e[1], st))
-        loop.synchronize()
+        loop.synchronize(check=False)
         t_inflight = ev.avg_ms()
         ev.close()
+        chain_ok()
         # the stage kernels and the step kernel alone are timed on a serial loop of the same shape
         del loop
         if xchg is not None:
@@ -506,7 +528,7 @@ def run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, stage_
                       "allgather_track_tables": (("per-frame" if xchg.per_frame else "window-end") if xchg is not None else False),
                       "allgather_impl": (("av_allgather_tracks (RCCL)" if xchg.native else "torch.distributed") if xchg is not None else None),
                       "fused_step": bool(loop.fused_step), "overlapped_steps": ov, "steps_per_library_call": unit,
-                      "stream_sets_tried_us_per_step": tuned, "overlap_fallback": fallback,
+                      "stream_sets_tried_us_per_step": tuned,
                       "parallelism": "stream-sharded x%d" % world},
            "roofline": roof, "kernels": finish_kernel_list(ks),
            "step": {"critical_branch": "side (detect+track)" if side > main else "main (kf+plan)",
@@ -807,11 +829,8 @@ def main():
     def hot(name, S, W, graph, steps, warmup, overlap=None):
         try:
             return run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, overlap=overlap)
-        except RuntimeError as e:
-            # an overlapped loop reports a step that waited in vain for its predecessor (kernels of different streams not running
-            # concurrently: a serialising tool, a device shared with another process): the same measurement with serial launches
-            if "waited in vain" not in str(e) or overlap == 1 or world > 1:
-                raise
+        except ChainBroken as e:
+            # (raised on every rank together) the same measurement with serial launches
             r = run_hot_loop(a, world, rank, local, name, S, W, graph, steps, warmup, overlap=1)
             r["config"]["overlap_fallback"] = str(e)[:200]
             return r
