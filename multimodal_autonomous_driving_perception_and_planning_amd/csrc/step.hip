@@ -122,10 +122,11 @@ __device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
 }
 // n8 8-byte words of a stream's record into LDS, by the first `nthreads` threads of the workgroup.  coherent: device-scope loads (the
 // record was written by the previous step, possibly on another XCD).
-__device__ __forceinline__ void fetch_record(const void* src, void* dst_lds, int n8, int nthreads, bool coherent) {
+__device__ __forceinline__ void fetch_record(const void* src, void* dst_lds, int n8, int first, int end, bool coherent) {
     unsigned long long* g = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(src));
     unsigned long long* l = reinterpret_cast<unsigned long long*>(dst_lds);
-    for (int i = threadIdx.x; i < n8; i += nthreads)
+    if ((int)threadIdx.x < first || (int)threadIdx.x >= end) return;
+    for (int i = (int)threadIdx.x - first; i < n8; i += end - first)
         l[i] = coherent ? __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[i];
 }
 
@@ -160,23 +161,14 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
                                a.det_status ? a.det_status + s : nullptr);
         }
         ck.mark(0);                   // detections made
-        if (seq) {
-            if (!seq_enter(a, 2 * s, &go)) return;
-        } else {
-            __syncthreads();
-        }
+        if (seq && !seq_enter(a, 2 * s, &go)) return;
         ck.mark(1);                   // waited for the predecessor
-        if (tid < a.dcap) {           // the detections' output arrays (the tracker reads the LDS copy)
-            reinterpret_cast<int4*>(a.det_box)[(size_t)s * a.dcap + tid] = reinterpret_cast<const int4*>(d_box)[tid];
-            a.det_cls[(size_t)s * a.dcap + tid] = d_cls[tid];
-            a.det_conf[(size_t)s * a.dcap + tid] = d_conf[tid];
-            if (tid == 0) a.det_n[s] = d_n[0];
-        }
         unsigned char* stage = smem + a.stage_off;
         int fc0 = 0;
         if (seq && tid == 0) fc0 = __hip_atomic_load(a.frame_count + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (in flight with the table)
+        // (by the waves thread 0 is not in: launched serially, the record comes in while thread 0 still makes the detections)
         fetch_record(a.trk_state + (size_t)s * state_bytes(a.tcap, a.tcfg.trajectory_length), stage,
-                     (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, STEP_NW * 64, seq);
+                     (HDR_INTS * 4 + a.tcap * (int)sizeof(av_track_row)) / 8, 64, STEP_NW * 64, seq);
         if (tid == 0) {
             if (seq) {
                 if (fc0 != fc_before) atomicOr(a.flags + flag_fault(a.S), 2);
@@ -185,8 +177,14 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
                 a.frame_count[s] = fc_stage;
             }
         }
-        __syncthreads();              // the detections are in memory and visible to this workgroup (fence + vmcnt(0)); the table copy is in LDS
+        __syncthreads();              // the detections and the table copy are in LDS
         ck.mark(2);                   // record in LDS
+        if (tid < a.dcap) {           // the detections' output arrays (the tracker reads the LDS copy)
+            reinterpret_cast<int4*>(a.det_box)[(size_t)s * a.dcap + tid] = reinterpret_cast<const int4*>(d_box)[tid];
+            a.det_cls[(size_t)s * a.dcap + tid] = d_cls[tid];
+            a.det_conf[(size_t)s * a.dcap + tid] = d_conf[tid];
+            if (tid == 0) a.det_n[s] = d_n[0];
+        }
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
                                         a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0);
         ck.mark(3);                   // tracker frame (thread 0's wave)
@@ -211,7 +209,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         ck.mark(1);
         if (tid < 64) {
             double* rec = a.kf_state + (size_t)s * AV_KF_STATE_DOUBLES;
-            fetch_record(rec, kf_stage, AV_KF_STATE_DOUBLES, 64, seq);
+            fetch_record(rec, kf_stage, AV_KF_STATE_DOUBLES, 0, 64, seq);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
