@@ -54,9 +54,9 @@ constexpr int STEP_NW = 8;
 //   * Instead the few bytes that cross a step boundary -- tracker: header + rows (4 160 B) and the frame counter; Kalman: 46 doubles
 //     -- are WRITTEN with device-scope stores (sc1: written through to memory) and READ once, into LDS, with device-scope loads (sc1:
 //     never served from the CU's L1 or from an XCD's possibly stale L2 line); the stage code runs on the LDS copy.  Nothing else a
-//     role reads was written by the previous step.  The publisher's counter store follows a workgroup barrier behind those stores
-//     (s_waitcnt vmcnt(0) in every wave: they are acknowledged, i.e. visible device-wide); the consumer's loads are issued after its
-//     poll has returned the new count.  tests/test_gpu_step.py: 150 unsynchronised steps x 64 streams bit-identical to the serial loop.
+//     role reads was written by the previous step.  The publisher's counter store follows an explicit s_waitcnt vmcnt(0) in every
+//     wave (the record's stores are acknowledged, i.e. visible device-wide) and a workgroup barrier; the consumer's loads are issued
+//     after its poll has returned the new count.  tests/test_gpu_step.py: 150 unsynchronised steps x 64 streams bit-identical to the serial loop.
 // The per-step outputs (detections, snapshot rows, det2trk, Kalman output, waypoints, costs, order) alternate between two buffer
 // sets on the host side, so steps t and t + 1 never write the same output and the Kalman counter moves on before the planner
 // has run.  At most two steps are in flight (two streams), both fit on the chip together (4 S workgroups of <= 64 KB), and every
@@ -188,6 +188,10 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
                                         a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0);
         ck.mark(3);                   // tracker frame (thread 0's wave)
+        // Every wave waits for ITS OWN stores to be acknowledged before the barrier: __syncthreads() orders the workgroup's LDS and
+        // L1 traffic (s_waitcnt lgkmcnt(0) + s_barrier on this target), it does not wait for global stores -- and the counter thread 0
+        // stores behind the barrier must not overtake another wave's record.
+        if (seq) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
         if (seq || a.wire) __syncthreads();      // every wave's stores (table, rings, counters, snapshot rows) are complete
         ck.mark(4);                   // all waves done, stores acknowledged
         // the successor may start before the wire table is written: the steps in flight have wire buffers of their own
@@ -230,6 +234,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             }
         }
         ck.mark(3);                   // Kalman step + record written
+        if (seq) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the record's stores are acknowledged before the barrier (see the tracker role)
         __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
         ck.mark(4);
         if (seq && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
