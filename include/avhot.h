@@ -491,7 +491,8 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
  *              1 Kalman) of stream s, a 128-byte line each; [64 S] = 0, the fault word -- bit 0: a workgroup's wait ran out
  *              (AVHOT_STEP_SPIN polls, default 2^22: a predecessor that was never launched) and it left without running its step,
  *              bit 1: frame_count[s] was not base + seq; check it after synchronising; [64 S + 32 + s] = frame_count[s] at the
- *              reset (the detections of step seq are made for frame count base + seq + 1 without waiting for step seq - 1).
+ *              reset (the detections of step seq are made for frame count base + seq + 1 without waiting for step seq - 1);
+ *              the last 64 ints: phase clocks summed by the kernel when AVHOT_STEP_FENCE=8 (tools/steptime.py), otherwise unused.
  * `depth` = D: up to D launches may be in flight, each possibly waiting for the one before it, so all of them must be RESIDENT
  * together: the call picks sixteen or eight waves per workgroup accordingly and returns AV_EINVAL when D launches of 2 S workgroups
  * cannot fit (64 streams: D <= 2 with sixteen waves, <= 4 with eight).  HotLoop(window=1, overlap=D) drives it. */
