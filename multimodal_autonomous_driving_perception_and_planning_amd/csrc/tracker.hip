@@ -68,10 +68,9 @@ struct Shared {
     int misc[4];
 };
 
-// Workgroup synchronisation that orders LDS traffic only.  __syncthreads() would also drain every
-// outstanding global store (s_waitcnt vmcnt(0)) -- a full HBM round trip per frame for nothing, since
-// the per-frame outputs are write-only.  A single-wave workgroup needs no barrier at all: one wave's
-// DS operations execute in issue order.
+// Workgroup synchronisation that orders LDS traffic only (a fence on the "local" address space: no wait on
+// outstanding global stores whatever the compiler makes of a full __syncthreads(); the per-frame outputs are
+// write-only).  A single-wave workgroup needs no barrier at all: one wave's DS operations execute in issue order.
 template <bool MULTIWAVE>
 __device__ __forceinline__ void lds_sync() {
     if (MULTIWAVE) {
