@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
                 a.frame_count[s] = fc_stage;
             }
         }
+        if (seq) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): thread 0's frame-counter store is acknowledged before any wave passes the barrier
         __syncthreads();              // the detections and the table copy are in LDS
         ck.mark(2);                   // record in LDS
         if (tid < a.dcap) {           // the detections' output arrays (the tracker reads the LDS copy)
@@ -186,18 +187,15 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             if (tid == 0) a.det_n[s] = d_n[0];
         }
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
-                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0);
+                                        a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0,
+                                        seq ? a.flags + 32 * (2 * s) : nullptr, a.seq + 1, (a.fence & 8) != 0);
+        // (overlapped: the wave that keeps the complete rows has published the step counter itself, behind an s_waitcnt vmcnt(0) on its
+        // record stores -- __syncthreads() compiles to s_waitcnt lgkmcnt(0) + s_barrier on this target and waits for no global store --
+        // and written the snapshot rows after that; the successor may start before the wire table is written: the steps in flight have
+        // wire buffers of their own)
         ck.mark(3);                   // tracker frame (thread 0's wave)
-        // Every wave waits for ITS OWN stores to be acknowledged before the barrier: __syncthreads() orders the workgroup's LDS and
-        // L1 traffic (s_waitcnt lgkmcnt(0) + s_barrier on this target), it does not wait for global stores -- and the counter thread 0
-        // stores behind the barrier must not overtake another wave's record.
-        if (seq) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-        if (seq || a.wire) __syncthreads();      // every wave's stores (table, rings, counters, snapshot rows) are complete
-        ck.mark(4);                   // all waves done, stores acknowledged
-        // the successor may start before the wire table is written: the steps in flight have wire buffers of their own
-        if (seq && tid == 0) seq_leave(a, 2 * s);
-        ck.mark(5);
         if (a.wire) {                 // this stream's table in wire format (pack_tracks_kernel's row conversion)
+            __syncthreads();          // the snapshot rows the bookkeeper wave wrote
             // frame = frame0 + the stream's detector frame count after this step (a captured graph -- fixed kernel arguments -- stamps
             // every replay with its own index)
             if (tid < a.tcap)

@@ -102,7 +102,11 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                                av_track_row* __restrict__ snap, int32_t* __restrict__ snap_n,
                                int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
                                const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr,
-                               const bool coherent_out = false, const long long det_sf0 = -1) {
+                               const bool coherent_out = false, const long long det_sf0 = -1, int* publish_flag = nullptr,
+                               const int publish_value = 0, const bool publish_clock = false) {
+    // publish_flag (n_frames == 1 only; the overlapped time-step): the wave that keeps the complete rows stores publish_value there as
+    // soon as the stream's record (rows + header) is written AND acknowledged, and writes the frame's outputs (snapshot rows, det2trk)
+    // after that -- the successor launch waits for the record, not for the outputs
     // det_sf0 >= 0 (replica kernel): the detection arrays are indexed from this frame slot instead of s * n_frames (the one-launch
     // time-step hands over the LDS copy its detector role wrote, slot 0)
     // init_src: where the stream's header and rows are read from at entry instead of its state record (the one-launch time-step of
@@ -359,7 +363,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
 
         TRK_STAMP(6)                                        // deaths
         // ---- per-frame outputs --------------------------------------------------------------------
-        if (full) emit(sf);
+        if (full && !publish_flag) emit(sf);
         lds_sync<MULTIWAVE>();          // sh.d* are rewritten by the next frame
         TRK_STAMP(7)                                        // outputs
     };
@@ -697,6 +701,16 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
         } else {
             hdr[0] = T, hdr[1] = next_id, hdr[2] = frame_count, hdr[3] = status;
         }
+    }
+    if (publish_flag) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's stores (history rings, rows, header) are acknowledged
+        if (lane == 0) {
+            if (publish_clock)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(publish_flag + 2), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(publish_flag, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        emit((size_t)s * n_frames + (n_frames - 1));
     }
 }
 

@@ -13,11 +13,11 @@ print("stream sets tried:", lp.tune_streams())
 lp.load_measurements(np.stack([np.asarray(generate_ego_motion(64, seed=s), np.float64)[:1] for s in range(S)]), all_sets=True)
 lp.enqueue_steps(200); lp.synchronize()
 base = 65 * S + 32
-lp.seq_flags[base:].zero_(); torch.cuda.synchronize()
+lp.seq_flags[base:base + 64].zero_(); torch.cuda.synchronize()
 t0 = time.perf_counter(); lp.enqueue_steps(N); lp.synchronize(); dt = (time.perf_counter() - t0) / N * 1e6
-st = lp.seq_flags[base:].cpu().numpy().view(np.uint64).reshape(2, 16).astype(np.float64)
+st = lp.seq_flags[base:base + 64].cpu().numpy().view(np.uint64).reshape(2, 16).astype(np.float64)
 print("depth %d: %.2f us per step (with the clock stamps)" % (D, dt))
-names = [["detections", "wait for predecessor", "record -> LDS (+barrier)", "tracker frame", "wire + barrier (stores acked)", "publish", "-"],
+names = [["detections", "wait for predecessor", "record -> LDS (+barrier)", "tracker frame, record out + acknowledged, counter, outputs", "-", "-", "-"],
          ["-", "wait for predecessor", "record -> LDS", "Kalman + record out", "barrier", "-", "publish + planner"]]
 for r, role in enumerate(("tracker role", "Kalman / planner role")):
     n = st[r, 15]
