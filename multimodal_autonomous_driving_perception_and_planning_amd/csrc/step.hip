@@ -91,11 +91,15 @@ __device__ void StepClock::start(const StepArgs& a, int role) {
 __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) {
     if (threadIdx.x == 0) {
         int ok = 0;
-        for (int n = 0; n <= a.spin; ++n) {
-            if (__hip_atomic_load(a.flags + 32 * slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.seq) { ok = 1; break; }
+        // (locals: with the arguments read through `a` inside the loop the compiler reloads them from the kernel-argument segment on
+        // every poll, a scalar-cache round trip in front of each device-scope load)
+        int* const counter = a.flags + 32 * slot;
+        int* const fault = a.flags + flag_fault(a.S);
+        const int want = a.seq, spin = a.spin;
+        for (int n = 0; n <= spin; ++n) {
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
             // (once any wait has run out the chain is broken for good: the launches behind it give up at once instead of one timeout each)
-            if ((n & 255) == 255 && __hip_atomic_load(a.flags + flag_fault(a.S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(1);
+            if ((n & 255) == 255 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         }
         if (!ok) atomicOr(a.flags + flag_fault(a.S), 1);
         if (ok && (a.fence & 8) && a.seq > 0) {      // debug: publisher's clock at its counter store -> this poll's return
