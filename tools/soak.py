@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Soak test of the overlapped time-steps: N steps of 64 streams enqueued without any host synchronisation at depth 2, 3 and 4, the final
+tracker tables / history rings / filter records / frame counters compared bit for bit with the serial loop's.  Every step's table
+depends on all steps before it (ids, ages, rings), so one torn or stale hand-over anywhere shows at the end.
+usage: python tools/soak.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
+from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion
+S, N = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+z = np.stack([np.asarray(generate_ego_motion(64, seed=s), np.float64)[:1] for s in range(S)])
+offs = [17 * s for s in range(S)]
+
+
+def final(lp):
+    lp.synchronize()
+    hdr, rows, hist = lp.tracker_tables()
+    return dict(hdr=hdr, rows=rows.view(np.uint8), hist=hist, kf=lp.kf_state.cpu().numpy(), fc=lp.frame_count.cpu().numpy(),
+                cost=lp.cost.cpu().numpy(), order=lp.order.cpu().numpy(), vstate=lp.vstate.cpu().numpy())
+
+
+ref = HotLoop(n_streams=S, window=1)
+ref.reset(frame_offsets=offs)
+ref.load_measurements(z)
+t0 = time.perf_counter()
+for _ in range(N):
+    ref.enqueue_step()
+want = final(ref)
+print("serial: %d steps, %.2f us per step" % (N, (time.perf_counter() - t0) / N * 1e6), flush=True)
+del ref
+bad = 0
+for D in (4, 3, 2):
+    lp = HotLoop(n_streams=S, window=1, overlap=D)
+    lp.tune_streams()
+    lp.reset(frame_offsets=offs)
+    lp.load_measurements(z, all_sets=True)
+    t0 = time.perf_counter()
+    left = N
+    while left:
+        n = min(left, 50000)
+        lp.enqueue_steps(n)
+        left -= n
+    got = final(lp)
+    dt = (time.perf_counter() - t0) / N * 1e6
+    diff = [k for k in want if not np.array_equal(np.ascontiguousarray(want[k]).view(np.uint8), np.ascontiguousarray(got[k]).view(np.uint8))]
+    print("depth %d: %d steps, %.2f us per step, %s" % (D, N, dt, "identical to the serial loop" if not diff else "DIFFERS in %s" % diff), flush=True)
+    bad += bool(diff)
+    del lp
+sys.exit(1 if bad else 0)
