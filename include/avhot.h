@@ -493,6 +493,8 @@ int av_hot_step(av_ctx* ctx, av_stream_t stream, const av_tracker_cfg* tracker_c
  *              bit 1: frame_count[s] was not base + seq; check it after synchronising; [64 S + 32 + s] = frame_count[s] at the
  *              reset (the detections of step seq are made for frame count base + seq + 1 without waiting for step seq - 1);
  *              the last 64 ints: phase clocks summed by the kernel when AVHOT_STEP_FENCE=8 (tools/steptime.py), otherwise unused.
+ * Step numbers are 32-bit and wrap (a signed int carrying an unsigned count: 2^31 - 1 is followed by -2^31, -1 by 0); the stream and
+ * buffer set of step seq are those of (uint32_t)seq % D.
  * `depth` = D: up to D launches may be in flight, each possibly waiting for the one before it, so all of them must be RESIDENT
  * together: the call picks sixteen or eight waves per workgroup accordingly and returns AV_EINVAL when D launches of 2 S workgroups
  * cannot fit (64 streams: D <= 2 with sixteen waves, <= 4 with eight).  HotLoop(window=1, overlap=D) drives it. */

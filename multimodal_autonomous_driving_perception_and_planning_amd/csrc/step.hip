@@ -97,12 +97,13 @@ __device__ __forceinline__ bool seq_enter(const StepArgs& a, int slot, int* go) 
         int* const fault = a.flags + flag_fault(a.S);
         const int want = a.seq, spin = a.spin;
         for (int n = 0; n <= spin; ++n) {
-            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
+            // (step numbers are 32-bit and wrap -- three hours of stepping at this rate -- so "has reached" is a signed distance)
+            if ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)want) >= 0) { ok = 1; break; }
             // (once any wait has run out the chain is broken for good: the launches behind it give up at once instead of one timeout each)
             if ((n & 255) == 255 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         }
         if (!ok) atomicOr(a.flags + flag_fault(a.S), 1);
-        if (ok && (a.fence & 8) && a.seq > 0) {      // debug: publisher's clock at its counter store -> this poll's return
+        if (ok && (a.fence & 8) && a.seq != 0) {      // debug: publisher's clock at its counter store -> this poll's return
             const unsigned long long tp = __hip_atomic_load(reinterpret_cast<unsigned long long*>(a.flags + 32 * slot + 2), __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -122,7 +123,7 @@ __device__ __forceinline__ void seq_leave(const StepArgs& a, int slot) {
     if (a.fence & 8)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.flags + 32 * slot + 2), __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(a.flags + 32 * slot, a.seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.flags + 32 * slot, (int)((unsigned)a.seq + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // n8 8-byte words of a stream's record into LDS, by the first `nthreads` threads of the workgroup.  coherent: device-scope loads (the
 // record was written by the previous step, possibly on another XCD).
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         // q - 1 (tid 0 checks that against the counter the predecessor left: fault bit 1)
         int fc_before = 0;
         if (tid == 0) {
-            fc_before = seq ? a.flags[flag_base(a.S) + s] + a.seq : a.frame_count[s];
+            fc_before = seq ? (int)((unsigned)a.flags[flag_base(a.S) + s] + (unsigned)a.seq) : a.frame_count[s];
             fc_stage = fc_before;
             simdet_frame<true>(0, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, d_n, d_box, d_cls, d_conf,
                                a.det_status ? a.det_status + s : nullptr);
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         }
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
                                         a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0,
-                                        seq ? a.flags + 32 * (2 * s) : nullptr, a.seq + 1, (a.fence & 8) != 0);
+                                        seq ? a.flags + 32 * (2 * s) : nullptr, (int)((unsigned)a.seq + 1u), (a.fence & 8) != 0);
         // (overlapped: the wave that keeps the complete rows has published the step counter itself, behind an s_waitcnt vmcnt(0) on its
         // record stores -- __syncthreads() compiles to s_waitcnt lgkmcnt(0) + s_barrier on this target and waits for no global store --
         // and written the snapshot rows after that; the successor may start before the wire table is written: the steps in flight have
@@ -356,7 +357,7 @@ extern "C" int av_hot_step_seq(av_ctx* ctx, av_stream_t stream, const av_tracker
                                int32_t* det2trk, const double* z, double* kf_state, double* vstate, double* plan_state,
                                double* waypoints, double* cost, int32_t* order, void* wire, int stream0, int frame0,
                                int32_t* seq_flags, int seq, int depth) {
-    AV_REQUIRE(seq_flags && seq >= 0, AV_EINVAL, "av_hot_step_seq: needs the sequence flags (AV_STEP_FLAG_INTS(n_streams) int32) and seq >= 0");
+    AV_REQUIRE(seq_flags, AV_EINVAL, "av_hot_step_seq: needs the sequence flags (AV_STEP_FLAG_INTS(n_streams) int32)");
     AV_REQUIRE(depth >= 2 && depth <= AV_STEP_MAX_DEPTH, AV_EINVAL, "av_hot_step_seq: depth %d not in [2, %d]", depth, AV_STEP_MAX_DEPTH);
     return hot_step_launch(ctx, stream, tcfg, kcfg, n_streams, h, w, dcap, tcap, frame_count, det_n, det_box, det_cls, det_conf, det_status,
                            tracker_state, snap, snap_n, det2trk, z, kf_state, vstate, plan_state, waypoints, cost, order, wire, stream0,
@@ -367,7 +368,7 @@ extern "C" int av_hot_steps_seq(av_ctx* ctx, int depth, const av_stream_t* strea
                                 int n_streams, int h, int w, int dcap, int tcap, int32_t* frame_count, int32_t* det_status,
                                 void* tracker_state, double* kf_state, const av_step_set* sets, const double* z_steps, void* wire_steps,
                                 int stream0, int frame0, int32_t* seq_flags, int seq0, int n_steps) {
-    AV_REQUIRE(seq_flags && seq0 >= 0 && n_steps > 0 && sets && streams, AV_EINVAL, "av_hot_steps_seq: bad argument");
+    AV_REQUIRE(seq_flags && n_steps > 0 && sets && streams, AV_EINVAL, "av_hot_steps_seq: bad argument");
     AV_REQUIRE(depth >= 2 && depth <= AV_STEP_MAX_DEPTH, AV_EINVAL, "av_hot_steps_seq: depth %d not in [2, %d]", depth, AV_STEP_MAX_DEPTH);
     for (int k = 0; k < depth; ++k)
         for (int j = 0; j < k; ++j)
@@ -384,7 +385,7 @@ extern "C" int av_hot_steps_seq(av_ctx* ctx, int depth, const av_stream_t* strea
     }
     const size_t zb = (size_t)n_streams * 4, wb = (size_t)n_streams * (AV_WIRE_HDR_BYTES + (size_t)tcap * AV_WIRE_ROW_BYTES);
     for (int i = 0; i < n_steps; ++i) {
-        const int q = seq0 + i, k = q % depth;
+        const int q = (int)((unsigned)seq0 + (unsigned)i), k = (int)((unsigned)q % (unsigned)depth);      // (32-bit step numbers wrap)
         StepArgs& a = par[k];
         a.seq = q;
         if (z_steps) a.z = z_steps + (size_t)i * zb;

@@ -94,7 +94,7 @@ class HotLoop:
                                                                    for _ in range(self.overlap - 1)]
             self._pstreams = [self.stream] + [torch.cuda.Stream(device=d) for _ in range(self.overlap - 1)]
             self.seq_flags = torch.zeros(65 * S + 32 + 64, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
-            self._seq = 0
+            self._seq, self._stepped = 0, False
             self._csets = None
             self.reset()
             try:                              # (one step now: the library refuses a depth whose launches would not all be resident)
@@ -111,6 +111,12 @@ class HotLoop:
     @property
     def _s(self):
         return C.c_void_p(self.stream.cuda_stream)
+
+    @staticmethod
+    def _i32(v):
+        """A step number (kept modulo 2^32) as the signed int the C ABI takes."""
+        v &= 0xFFFFFFFF
+        return v - (1 << 32) if v & 0x80000000 else v
 
     def _serial_only(self, what):
         if self.overlap != 1:
@@ -133,7 +139,7 @@ class HotLoop:
                 self.seq_flags.zero_()
                 self.seq_flags[64 * self.S + 32:65 * self.S + 32].copy_(self.frame_count)
         if self.overlap > 1:
-            self._seq = 0
+            self._seq, self._stepped = 0, False
             self.__dict__.update(self._sets[0])
         self.stream.synchronize()
 
@@ -267,7 +273,7 @@ class HotLoop:
         role by the sequence flags (av_hot_step_seq)."""
         if stream is not None:
             raise RuntimeError("overlap=2.. launches on the loop's own streams")
-        k = self._seq % self.overlap
+        k = self._seq % self.overlap         # (_seq is kept modulo 2^32: the library's step numbers are 32-bit and wrap)
         b = self._sets[k]
         self.__dict__.update(b)              # the attributes name the set of the step enqueued last
         nat.check(self.L.av_hot_step_seq(self.ctx.handle, C.c_void_p(self._pstreams[k].cuda_stream), C.byref(self.tcfg), C.byref(self.kcfg),
@@ -276,8 +282,9 @@ class HotLoop:
                                          nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(b.get("snap")), nat.ptr(b.get("snap_n")),
                                          nat.ptr(b["det2trk"]), nat.ptr(b["z"]), nat.ptr(self.kf_state), nat.ptr(b["vstate"]),
                                          nat.ptr(b["plan_state"]), nat.ptr(b.get("wp")), nat.ptr(b["cost"]), nat.ptr(b["order"]),
-                                         nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq, self.overlap))
-        self._seq += 1
+                                         nat.ptr(self.wire), self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._i32(self._seq), self.overlap))
+        self._seq = (self._seq + 1) & 0xFFFFFFFF
+        self._stepped = True
 
     def enqueue_steps(self, n_steps, z_steps=None, wire_steps=None):
         """overlap=2: n_steps consecutive steps enqueued by one library call (av_hot_steps_seq: the launch loop in C).
@@ -304,9 +311,10 @@ class HotLoop:
                                           C.byref(self.tcfg), C.byref(self.kcfg), self.S, self.h, self.w, self.dcap, self.tcap,
                                           nat.ptr(self.frame_count), nat.ptr(self.det_status), nat.ptr(self.trk_state), nat.ptr(self.kf_state),
                                           self._csets, nat.ptr(z_steps), nat.ptr(wire_steps),
-                                          self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._seq, int(n_steps)))
-        self._seq += int(n_steps)
-        self.__dict__.update(self._sets[(self._seq - 1) % self.overlap])
+                                          self._wire_ids[0], self._wire_ids[1], nat.ptr(self.seq_flags), self._i32(self._seq), int(n_steps)))
+        self._seq = (self._seq + int(n_steps)) & 0xFFFFFFFF
+        self._stepped = True
+        self.__dict__.update(self._sets[((self._seq - 1) & 0xFFFFFFFF) % self.overlap])
 
     def tune_streams(self, pool=8, candidates=12, steps=600):
         """overlap=D: pick the D HIP streams the overlapped steps run on.  The runtime serves a process's streams from a few hardware
@@ -344,7 +352,7 @@ class HotLoop:
 
     def step_stream(self):
         """The torch stream the step enqueued last runs on (overlap=2 alternates between two)."""
-        return self._pstreams[(self._seq - 1) % self.overlap] if self.overlap > 1 and self._seq else self.stream
+        return self._pstreams[((self._seq - 1) & 0xFFFFFFFF) % self.overlap] if self.overlap > 1 and self._stepped else self.stream
 
     def enqueue_step(self):
         """One window of the whole loop: fork{detect; track} || {kf; plan}; join.  Detections only feed the
