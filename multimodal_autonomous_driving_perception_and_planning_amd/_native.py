@@ -216,6 +216,17 @@ def register(sigs):
             fn.argtypes = args
 
 
+def step_flag_ints(n_streams):
+    """AV_STEP_FLAG_INTS(n_streams) of include/avhot.h: int32 words of the overlapped steps' sequence flags."""
+    return 65 * n_streams + 32 + 64
+
+
+def step_i32(v):
+    """A step number (kept modulo 2^32) as the signed int the C ABI takes."""
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
 class StepSet(C.Structure):
     """av_step_set: the per-step buffers of one parity (av_hot_steps_seq)."""
     _fields_ = [(k, C.c_void_p) for k in ("det_n", "det_box", "det_cls", "det_conf", "snap", "snap_n", "det2trk", "z", "vstate",

@@ -93,7 +93,7 @@ class HotLoop:
             self._sets = [{k: getattr(self, k) for k in names}] + [{k: torch.zeros_like(getattr(self, k)) for k in names}
                                                                    for _ in range(self.overlap - 1)]
             self._pstreams = [self.stream] + [torch.cuda.Stream(device=d) for _ in range(self.overlap - 1)]
-            self.seq_flags = torch.zeros(65 * S + 32 + 64, dtype=i32, device=d)      # AV_STEP_FLAG_INTS
+            self.seq_flags = torch.zeros(nat.step_flag_ints(S), dtype=i32, device=d)
             self._seq, self._stepped = 0, False
             self._csets = None
             self.reset()
@@ -112,11 +112,7 @@ class HotLoop:
     def _s(self):
         return C.c_void_p(self.stream.cuda_stream)
 
-    @staticmethod
-    def _i32(v):
-        """A step number (kept modulo 2^32) as the signed int the C ABI takes."""
-        v &= 0xFFFFFFFF
-        return v - (1 << 32) if v & 0x80000000 else v
+    _i32 = staticmethod(nat.step_i32)
 
     def _serial_only(self, what):
         if self.overlap != 1:
