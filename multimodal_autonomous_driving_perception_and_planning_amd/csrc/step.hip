@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
     // the step's inputs that do not come from the previous step, in LDS before the wait: the frame's detections (made here, copied
     // to their output arrays by the other threads) and the ego measurement
     __shared__ __attribute__((aligned(16))) int d_box[8 * 4];
-    __shared__ __attribute__((aligned(16))) double d_conf[8], z_stage[4];
+    __shared__ __attribute__((aligned(16))) double d_conf[8], d_area[8], z_stage[4];
     __shared__ int d_cls[8], d_n[1];
     const int tid = threadIdx.x;
     const bool seq = a.flags != nullptr;          // consecutive steps overlapped: wait for / publish to the neighbouring launches
@@ -164,6 +164,8 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             fc_stage = fc_before;
             simdet_frame<true>(0, 0, 0, a.h, a.w, a.dcap, &fc_stage, a.tab, a.cdf, d_n, d_box, d_cls, d_conf,
                                a.det_status ? a.det_status + s : nullptr);
+            for (int i = 0; i < a.dcap; ++i)      // the boxes' areas, as the tracker's chunk hand-over makes them (exact in float64)
+                d_area[i] = (double)(d_box[4 * i + 2] - d_box[4 * i]) * (double)(d_box[4 * i + 3] - d_box[4 * i + 1]);
         }
         ck.mark(0);                   // detections made
         if (seq && !seq_enter(a, 2 * s, &go)) return;
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
         }
         tracker_body<false, 8, STEP_NW>(a.tcfg, 1, a.dcap, d_n, d_box, d_cls, d_conf, a.tcap, a.trk_state, a.snap, a.snap_n,
                                         a.det2trk, 1, s, smem, 0xFEDCBA9876543210ull, stage, seq, 0,
-                                        seq ? a.flags + 32 * (2 * s) : nullptr, (int)((unsigned)a.seq + 1u), (a.fence & 8) != 0);
+                                        seq ? a.flags + 32 * (2 * s) : nullptr, (int)((unsigned)a.seq + 1u), (a.fence & 8) != 0, d_area);
         // (overlapped: the wave that keeps the complete rows has published the step counter itself, behind an s_waitcnt vmcnt(0) on its
         // record stores -- __syncthreads() compiles to s_waitcnt lgkmcnt(0) + s_barrier on this target and waits for no global store --
         // and written the snapshot rows after that; the successor may start before the wire table is written: the steps in flight have
@@ -237,10 +239,12 @@ __global__ void __launch_bounds__(PW * 64) hot_step_kernel(StepArgs a) {
             }
         }
         ck.mark(3);                   // Kalman step + record written
-        if (seq) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the record's stores are acknowledged before the barrier (see the tracker role)
-        __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
+        if (seq && tid < 64) {        // the Kalman wave publishes its counter itself, behind the acknowledgement of its record stores
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            if (tid == 0) seq_leave(a, 2 * s + 1);
+        }
         ck.mark(4);
-        if (seq && tid == 3 * 64) seq_leave(a, 2 * s + 1);      // (a wave with no part in the planner's first phase)
+        __syncthreads();              // the planner's start state (plan_state[s]) is in memory and visible to this workgroup
         plan_block<1, PW>(a.pp, s, a.S, a.plan_state, nullptr, 0, nullptr, 0, a.wp, a.cost, a.order, reinterpret_cast<double*>(smem));
         ck.mark(6);                   // planner (thread 0's wave)
     }

@@ -103,7 +103,9 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
                                int32_t* __restrict__ det2trk, int chunk_frames, const int s, unsigned char* smem,
                                const unsigned long long wave_map = 0xFEDCBA9876543210ull, const unsigned char* init_src = nullptr,
                                const bool coherent_out = false, const long long det_sf0 = -1, int* publish_flag = nullptr,
-                               const int publish_value = 0, const bool publish_clock = false) {
+                               const int publish_value = 0, const bool publish_clock = false, const double* det_area = nullptr) {
+    // det_area (replica kernel, n_frames == 1, det_sf0 == 0): the detection arrays ARE the staged frame -- they sit in this workgroup's
+    // LDS, complete with the boxes' areas, behind a barrier the caller has passed: no copy into the chunk buffer, no barriers around it
     // publish_flag (n_frames == 1 only; the overlapped time-step): the wave that keeps the complete rows stores publish_value there as
     // soon as the stream's record (rows + header) is written AND acknowledged, and writes the frame's outputs (snapshot rows, det2trk)
     // after that -- the successor launch waits for the record, not for the outputs
@@ -211,7 +213,7 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
         }
     };
     const size_t dsf0 = det_sf0 >= 0 ? (size_t)det_sf0 : (size_t)s * n_frames;
-    if (REPL && n_frames > 0) prefetch(dsf0, n_frames < FC ? n_frames : FC);
+    if (REPL && n_frames > 0 && !det_area) prefetch(dsf0, n_frames < FC ? n_frames : FC);
     int fl = -1;                               // frame within the staged chunk
     // TIMED (AVHOT_TRACKER_TIMED, tools/ktime.py): cycles of every wave of stream 0 by phase, summed over the window, left in det2trk
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -399,7 +401,10 @@ __device__ __forceinline__ void tracker_body(const av_tracker_cfg& cfg, int n_fr
     for (int f = 0; f < n_frames; ++f) {
         const size_t sf = (size_t)s * n_frames + f;
         fl = (fl + 1 == FC) ? 0 : fl + 1;
-        if (REPL && fl == 0) {
+        if (REPL && det_area) {
+            c_n = const_cast<int*>(det_n), c_box = const_cast<int*>(det_box), c_cls = const_cast<int*>(det_cls);
+            c_conf = const_cast<double*>(det_conf), c_area = const_cast<double*>(det_area);
+        } else if (REPL && fl == 0) {
             // the chunk was fetched into registers while the previous one was being processed (one element per
             // thread: FC * dcap <= 512): hand it to LDS and start fetching the next one
             lds_sync<true>();
