@@ -2,13 +2,15 @@
 """Soak test of the overlapped time-steps: N steps of 64 streams enqueued without any host synchronisation at depth 2, 3 and 4, the final
 tracker tables / history rings / filter records / frame counters compared bit for bit with the serial loop's.  Every step's table
 depends on all steps before it (ids, ages, rings), so one torn or stale hand-over anywhere shows at the end.
-usage: python tools/soak.py [steps]"""
+usage: python tools/soak.py [steps] [streams] [depths, e.g. 4,3,2]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from multimodal_autonomous_driving_perception_and_planning_amd.pipeline import HotLoop
 from multimodal_autonomous_driving_perception_and_planning_amd.harness import generate_ego_motion
-S, N = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+DEPTHS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [4, 3, 2]
 z = np.stack([np.asarray(generate_ego_motion(64, seed=s), np.float64)[:1] for s in range(S)])
 offs = [17 * s for s in range(S)]
 
@@ -30,7 +32,7 @@ want = final(ref)
 print("serial: %d steps, %.2f us per step" % (N, (time.perf_counter() - t0) / N * 1e6), flush=True)
 del ref
 bad = 0
-for D in (4, 3, 2):
+for D in DEPTHS:
     lp = HotLoop(n_streams=S, window=1, overlap=D)
     lp.tune_streams()
     lp.reset(frame_offsets=offs)
