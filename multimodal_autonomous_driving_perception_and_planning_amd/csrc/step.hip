@@ -11,8 +11,9 @@
 //                          wire table for the all-gather (exchange.hip's format), all from the same workgroup
 //   workgroups [S, 2 S)    stream s: Kalman step in the first wave (axis-separable filter; the dense filter on one lane for a
 //                          stream flagged non-separable), then the 3 C candidate trajectories spread over the workgroup's
-//                          eight waves (plan_block<1, 8>), cost ranking, outputs
+//                          sixteen (or eight) waves (plan_block<1, PW>), cost ranking, outputs
 // The two roles of a stream never exchange data (the planner does not consume tracks).
+// av_hot_step launches one such step; av_hot_step_seq / av_hot_steps_seq keep up to four consecutive steps in flight (below).
 #define AVHOT_DEVICE_ONLY
 #include "simdet.hip"
 #include "tracker.hip"
@@ -42,10 +43,10 @@ constexpr int STEP_NW = 8;
 // One launch per time-step leaves the chip to ONE kernel of 2 S workgroups whose 13 us are mostly latency (launch, first loads,
 // the Kalman -> arc length -> trajectories chain, the drain of the stores), and step t + 1 only starts when step t has drained.
 // What step t + 1 really needs of step t is less: its tracker role the stream's tracker table, its Kalman role the stream's
-// filter state -- not the planner's 4.5 MB of waypoints.  av_hot_step_seq therefore lets the caller launch steps alternately on
-// TWO HIP streams (step t + 2 follows step t in stream order) and orders step t + 1 behind step t per stream and role on the
-// device: a counter per stream and role (0 tracker, 1 Kalman) holds the number of steps whose role has finished.  A role of step q waits
-// until its counter reads q and publishes q + 1 when its persistent state is written.
+// filter state -- not the planner's 4.5 MB of waypoints.  av_hot_step_seq therefore lets the caller launch step q on HIP stream
+// q mod D of D = 2..4 streams (step q + D follows step q in stream order) and orders step q + 1 behind step q per stream and role
+// on the device: a counter per stream and role (0 tracker, 1 Kalman) holds the number of steps whose role has finished.  A role of
+// step q waits until its counter reads q and publishes q + 1 when its persistent state is written.
 // Steps land on different XCDs (measured: the predecessor's role had run on another XCD in 99.98 % of 537 600 hand-overs), each
 // with an L2 of its own, so the hand-over has to go through memory:
 //   * an agent-scope ACQUIRE in the consumer would be buffer_inv sc1, which drops the XCD's whole L2 -- that alone takes the
@@ -54,13 +55,16 @@ constexpr int STEP_NW = 8;
 //   * Instead the few bytes that cross a step boundary -- tracker: header + rows (4 160 B) and the frame counter; Kalman: 46 doubles
 //     -- are WRITTEN with device-scope stores (sc1: written through to memory) and READ once, into LDS, with device-scope loads (sc1:
 //     never served from the CU's L1 or from an XCD's possibly stale L2 line); the stage code runs on the LDS copy.  Nothing else a
-//     role reads was written by the previous step.  The publisher's counter store follows an explicit s_waitcnt vmcnt(0) in every
-//     wave (the record's stores are acknowledged, i.e. visible device-wide) and a workgroup barrier; the consumer's loads are issued
-//     after its poll has returned the new count.  tests/test_gpu_step.py: 150 unsynchronised steps x 64 streams bit-identical to the serial loop.
-// The per-step outputs (detections, snapshot rows, det2trk, Kalman output, waypoints, costs, order) alternate between two buffer
-// sets on the host side, so steps t and t + 1 never write the same output and the Kalman counter moves on before the planner
-// has run.  At most two steps are in flight (two streams), both fit on the chip together (4 S workgroups of <= 64 KB), and every
-// wait is bounded: after `spin` polls the workgroup sets the fault word (bit 0) and leaves without running its step
+//     role reads was written by the previous step.  The counter is stored by the wave that wrote the record (the tracker's row-keeping
+//     wave, the Kalman wave) behind an explicit s_waitcnt vmcnt(0): its stores are acknowledged, i.e. visible device-wide
+//     (__syncthreads() is s_waitcnt lgkmcnt(0) + s_barrier on this target and waits for no global store); the consumer's loads are
+//     issued after its poll has returned the new count.  tests/test_gpu_step.py: 150 unsynchronised steps x 64 streams at depth 2, 3, 4
+//     bit-identical to the serial loop; tools/soak.py: 10^6 steps.
+// The per-step outputs (detections, snapshot rows, det2trk, Kalman output, waypoints, costs, order, wire table) rotate through D
+// buffer sets on the host side, so steps in flight never write the same output and the Kalman counter moves on before the
+// planner has run.  All launches in flight must be RESIDENT together (each may be waiting for the one before it): hot_step_args picks
+// sixteen or eight waves per workgroup from the occupancy and refuses a depth that does not fit.  Every wait is bounded: after `spin`
+// polls the workgroup sets the fault word (bit 0) and leaves without running its step, the launches behind it give up at once
 // (HotLoop.synchronize raises) -- no launch can hang on a lost predecessor.
 // seq_flags layout (AV_STEP_FLAG_INTS): one 128-byte line per counter -- 2 S pollers hammer them -- then the fault word's line, then
 // the streams' detector frame counts at reset (the count before step q is base + q: the detections do not have to wait)
